@@ -1,0 +1,174 @@
+/*
+ * airvision.h -- C ABI of libairvision_hip.so, the MI355X (gfx950) implementation of
+ * UAV-Airvision's per-frame hot path.
+ *
+ * The reference (BUBLET/uav-airvision) is pure Python; its "FFI" for this path is the set of
+ * third-party native calls listed in SURVEY.md section 2.1 (K1-K13) plus the Python call surface of
+ * section 8(b).  Each entry point below names the reference interface it replaces (file:line,
+ * relative to the reference's src/).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions: every function returns 0 on success and a negative AV_E_*
+ * code on error, never throws; `*_dev` pointers are device (HBM) pointers, everything else is host
+ * memory owned by the caller and only read/written during the call; the library owns the device
+ * memory of a context; there is no process-global state; `stream` is a hipStream_t (NULL = the
+ * default stream).  Unless a function says it synchronises, work is only ENQUEUED on `stream`.
+ */
+#ifndef AIRVISION_H
+#define AIRVISION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AV_OK            0
+#define AV_E_INVALID    -1   /* bad argument / unsupported shape */
+#define AV_E_HIP        -2   /* a HIP runtime call failed (see av_last_error) */
+#define AV_E_CAPACITY   -3   /* a device-side capacity was exceeded (e.g. FAST corners > max_corners) */
+#define AV_E_NODEVICE   -4   /* no gfx950 device visible */
+
+#define AV_MAX_LEVELS    5   /* pyramid levels 0..4 (the reference uses maxLevel = 3, config.py:34) */
+#define AV_PYR_BORDER   16   /* border (pixels) of every padded pyramid level; >= LK win + 1 */
+
+/* Thread-local text of the last error raised on the calling thread. */
+const char* av_last_error(void);
+/* Library version / build info string. */
+const char* av_version(void);
+/* Number of visible HIP devices (does not initialise a context beyond the count). */
+int av_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Padded u8 pyramids.  A pyramid is one contiguous device allocation holding levels 0..levels-1,
+ * each level stored with an AV_PYR_BORDER-pixel BORDER_REFLECT_101 frame (what OpenCV's
+ * buildOpticalFlowPyramid produces internally for calcOpticalFlowPyrLK).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct av_pyr_layout {
+    int32_t levels;
+    int32_t w[AV_MAX_LEVELS], h[AV_MAX_LEVELS];      /* interior size of each level                */
+    int32_t pitch[AV_MAX_LEVELS];                    /* bytes per padded row                       */
+    int64_t offset[AV_MAX_LEVELS];                   /* byte offset of the padded level's (0,0)    */
+    int64_t bytes;                                   /* total bytes of one pyramid (16-B multiple) */
+} av_pyr_layout;
+
+int av_pyramid_layout(int w, int h, int levels, av_pyr_layout* out);
+
+/* Build n_img pyramids.  Image i is at img_dev + i*img_stride (tightly packed w*h u8), pyramid i
+ * at pyr_dev + i*pyr_stride.  Replaces the pyrDown chain inside cv2.calcOpticalFlowPyrLK
+ * (reference: image_processing/pyramid_builder.py:22-48 is a pass-through). */
+int av_pyramid_build(const uint8_t* img_dev, int64_t img_stride, int n_img, int w, int h, int levels,
+                     uint8_t* pyr_dev, int64_t pyr_stride, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * cv2.calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts, winSize=(win,win),
+ *   maxLevel=levels-1, criteria=(EPS|COUNT, max_iter, eps), flags=OPTFLOW_USE_INITIAL_FLOW)
+ * Reference call sites: image_processing/feature_tracker.py:102-108,
+ * image_processing/stereo_matcher.py:64-68 and 70-74, parameters config.py:31-44.
+ * Batched over n_set point sets: set i tracks count_dev[i] (<= cap) points from pyramid
+ * pyrI_dev + i*pyr_stride into pyrJ_dev + i*pyr_stride.  prev/next are float32 (x,y) pairs at
+ * [i*cap + k]; next holds the initial guess on entry and the result on return; status is u8.
+ * ------------------------------------------------------------------------------------------- */
+int av_lk_track(const uint8_t* pyrI_dev, const uint8_t* pyrJ_dev, int64_t pyr_stride, int n_set,
+                int w, int h, int levels,
+                const float* prev_dev, float* next_dev, uint8_t* status_dev, const int32_t* count_dev, int cap,
+                int win, int max_iter, double eps, double min_eig_threshold, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * cv2.FastFeatureDetector_create(threshold).detect(img, mask)   (TYPE_9_16, NMS on)
+ * Reference: image_processing/pipeline.py:23-25, feature_initializer.py:52, feature_adder.py:64.
+ * Batched over n_img tightly packed images (and optional masks, NULL = no mask).  For image i the
+ * number of keypoints is written to count_dev[i] and keypoint k is packed into
+ * kp_dev[i*cap + k] = score << 19 | (2^19 - 1 - (y*w + x)); keypoints are UNORDERED (sort the
+ * packed words descending within equal score to recover raster order).  Requires w*h <= 2^19.
+ * If more than cap keypoints exist count_dev[i] still reports the true number.
+ * ------------------------------------------------------------------------------------------- */
+int av_fast_detect(const uint8_t* img_dev, int64_t img_stride, const uint8_t* mask_dev, int64_t mask_stride,
+                   int n_img, int w, int h, int threshold, uint32_t* kp_dev, int32_t* count_dev, int cap,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * cv2.undistortPoints(pts, K, D, None, R, P = identity) for pinhole + radtan
+ * (reference: image_processing/camera_model.py:24-47, feature_publisher.py:24-59), and
+ * cv2.projectPoints(convertPointsToHomogeneous(pts), 0, 0, K, D)
+ * (reference: image_processing/camera_model.py:49-75).  fp64 in, fp64 out; intr = [fx fy cx cy],
+ * dist = [k1 k2 p1 p2], R = row-major 3x3 (host pointers, copied by value).
+ * ------------------------------------------------------------------------------------------- */
+int av_undistort_points(const double* pts_dev, int n, const double* intr, const double* dist, const double* R,
+                        double* out_dev, void* stream);
+int av_distort_points(const double* pts_dev, int n, const double* intr, const double* dist,
+                      double* out_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The image front-end as one device-resident engine over n_streams independent stereo streams:
+ * ImageProcessingPipeline.__init__ / imu_callback / stereo_callback
+ * (reference: image_processing/pipeline.py:15-40, 42-44, 46-150) with all of its feature_* stages
+ * (feature_initializer.py:45-85, feature_tracker.py:74-177, stereo_matcher.py:33-115,
+ * feature_adder.py:52-108, feature_pruner.py:8-19, feature_publisher.py:90-121,
+ * imu_processor.py:22-67).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct av_frontend_config {
+    int32_t width, height;                   /* config.cam0_resolution (config.py:102)             */
+    int32_t grid_row, grid_col;              /* config.py:23-24                                     */
+    int32_t grid_min_feature_num;            /* config.py:26                                        */
+    int32_t grid_max_feature_num;            /* config.py:27                                        */
+    int32_t fast_threshold;                  /* config.py:28                                        */
+    int32_t lk_win;                          /* config.patch_size (config.py:35)                    */
+    int32_t lk_levels;                       /* config.pyramid_levels + 1 (config.py:34)            */
+    int32_t lk_max_iter;                     /* config.max_iteration (config.py:31)                 */
+    int32_t max_corners;                     /* capacity for FAST keypoints of one image            */
+    int32_t reserved0;
+    double  lk_eps;                          /* config.track_precision (config.py:32)               */
+    double  lk_min_eig;                      /* OpenCV default minEigThreshold = 1e-4               */
+    double  stereo_threshold;                /* config.py:30                                        */
+    double  cam0_intrinsics[4], cam0_distortion[4];   /* config.py:99-101                           */
+    double  cam1_intrinsics[4], cam1_distortion[4];   /* config.py:118-120                          */
+    double  R_cam0_imu[9], R_cam1_imu[9];    /* inv(T_imu_cam*)[:3,:3] (imu_processor.py:10-16)     */
+    double  R0to1[9];                        /* R_cam1_imu.T @ R_cam0_imu (stereo_matcher.py:47)    */
+    double  E[9];                            /* skew(t01) @ R0to1 (stereo_matcher.py:90-91)         */
+    double  norm_unit;                       /* 4/(2fx+2fy) of cam0 (stereo_matcher.py:103-104)     */
+} av_frontend_config;
+
+typedef struct av_frontend av_frontend;
+
+int  av_frontend_create(const av_frontend_config* cfg, int n_streams, int device, av_frontend** out);
+void av_frontend_destroy(av_frontend* fe);
+
+/* ImageProcessingPipeline.imu_callback (pipeline.py:42-44 -> imu_processor.py:22-26).  Only the
+ * gyro is used by the front-end.  Thread-safe against av_frontend_step* on other threads. */
+int av_frontend_push_imu(av_frontend* fe, int stream, double timestamp, const double gyro[3]);
+
+/* ImageProcessingPipeline.stereo_callback for every stream at once (pipeline.py:46-150).
+ * Stream s reads its cam0/cam1 images (tightly packed width*height u8, device memory) at
+ * img0_dev + s*img_stride and img1_dev + s*img_stride; timestamps[s] is the frame time.  All
+ * kernels are enqueued on `stream`; nothing is synchronised. */
+int av_frontend_step(av_frontend* fe, const uint8_t* img0_dev, const uint8_t* img1_dev, int64_t img_stride,
+                     const double* timestamps, void* stream);
+/* Same with host images (the drop-in boundary hands over numpy arrays): copies H2D, steps. */
+int av_frontend_step_host(av_frontend* fe, const uint8_t* img0_host, const uint8_t* img1_host, int64_t img_stride,
+                          const double* timestamps, void* stream);
+
+/* Capacity (features per stream) of the published feature message = grid_num * grid_max. */
+int av_frontend_max_features(const av_frontend* fe);
+
+/* The feature_msg of the last step (feature_publisher.py:109-121), synchronising `stream` first.
+ * For stream s: n_out[s] features; ids at ids_out[s*cap + k]; (u0,v0,u1,v1) at uv_out[(s*cap+k)*4].
+ * cap must be >= av_frontend_max_features.  Returns AV_E_CAPACITY if any stream overflowed a
+ * device-side buffer during the step (results of that stream are then not parity-exact). */
+int av_frontend_read_features(av_frontend* fe, int64_t* ids_out, double* uv_out, int32_t* n_out, int cap, void* stream);
+
+/* Pipeline state visible to callers (pipeline.py:33-40): the grid of the frame just published
+ * (= prev_features after the callback returns).  Per feature k of stream `stream`:
+ * ids[k], lifetime[k], cell[k], pts[k*4] = cam0 x,y, cam1 x,y (pixels, float32).  Synchronises. */
+int av_frontend_read_grid(av_frontend* fe, int stream_idx, int64_t* ids, int32_t* lifetime, int32_t* cell,
+                          float* pts, int cap, int32_t* n_out, int64_t* next_feature_id, void* stream);
+
+/* Stage counters of the last step for one stream (feature_tracker.py:96,123,133,157 and the
+ * adder): [before_tracking, after_tracking, after_matching, n_fast_corners, n_candidates, n_new,
+ * n_published, overflow_flags].  Synchronises. */
+int av_frontend_read_counters(av_frontend* fe, int stream_idx, int32_t out[8], void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIRVISION_H */

@@ -1,0 +1,108 @@
+"""End-to-end parity of the device-resident front-end engine against the CPU oracle front-end:
+same seeded synthetic stereo+IMU streams, bit-exact feature ids and bit-exact (u0,v0,u1,v1)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_oracle(cfg, stream):
+    from oracle.frontend import OracleFrontend
+    from uav_airvision_amd.synth import replay
+    fe = OracleFrontend(cfg)
+    out = []
+
+    def on_frame(m):
+        msg = fe.stereo_callback(m)
+        ids = np.array([f.id for f in msg.features], np.int64)
+        uv = np.array([[f.u0, f.v0, f.u1, f.v1] for f in msg.features], np.float64).reshape(-1, 4)
+        out.append((ids, uv, dict(fe.num_features), dict(fe.debug.get('add', {}))))
+    replay(stream, [fe.imu_callback], on_frame)
+    return out
+
+
+def _run_engine(cfg, streams, max_corners=8192):
+    import torch
+    from uav_airvision_amd.frontend import FrontendEngine
+    eng = FrontendEngine(cfg, n_streams=len(streams), max_corners=max_corners)
+    out = [[] for _ in streams]
+    its = [iter(s.imu) for s in streams]
+    pend = [next(it, None) for it in its]
+    for k in range(streams[0].n_frames):
+        msgs = [s.frame(k) for s in streams]
+        for i, m in enumerate(msgs):
+            while pend[i] is not None and pend[i].timestamp <= m.timestamp:
+                eng.push_imu(i, pend[i].timestamp, pend[i].angular_velocity)
+                pend[i] = next(its[i], None)
+        img0 = torch.from_numpy(np.stack([m.cam0_image for m in msgs])).cuda()
+        img1 = torch.from_numpy(np.stack([m.cam1_image for m in msgs])).cuda()
+        eng.step(img0, img1, [m.timestamp for m in msgs])
+        feats = eng.read_features()
+        for i in range(len(streams)):
+            out[i].append((feats[i][0], feats[i][1], eng.read_counters(i)))
+    eng.close()
+    return out
+
+
+def _compare(ref, got, tag):
+    assert len(ref) == len(got)
+    for k, (r, g) in enumerate(zip(ref, got)):
+        ids_r, uv_r, nf, add = r
+        ids_g, uv_g, cnt = g
+        where = '%s frame %d' % (tag, k)
+        if k > 0:
+            assert cnt['before_tracking'] == nf['before_tracking'], where
+            assert cnt['after_tracking'] == nf['after_tracking'], where
+            assert cnt['after_matching'] == nf['after_matching'], where
+            assert cnt['n_fast'] == add['n_fast'], where
+            assert cnt['n_candidates'] == add['n_candidates'], where
+            assert cnt['n_new'] == add['n_new'], where
+        assert cnt['overflow'] == 0, where
+        assert np.array_equal(ids_r, ids_g), where
+        assert np.array_equal(uv_r.view(np.uint64), uv_g.view(np.uint64)), (where, np.abs(uv_r - uv_g).max())
+
+
+def test_engine_matches_oracle_two_streams_default_grid(cfg):
+    from uav_airvision_amd.synth import SyntheticStream
+    streams = [SyntheticStream(cfg, seed=s, n_frames=7) for s in (0, 1)]
+    got = _run_engine(cfg, streams)
+    for i, st in enumerate(streams):
+        ref = _run_oracle(cfg, st)
+        assert len(ref[0][0]) > 30 and len(ref[-1][0]) > 60
+        _compare(ref, got[i], 'stream %d' % i)
+
+
+def test_engine_matches_oracle_300_features_fast_motion():
+    """BASELINE configs[1] shape: grid 4x5 with 15 features per cell (300 tracked features)."""
+    from uav_airvision_amd.config import ConfigEuRoC
+    from uav_airvision_amd.synth import SyntheticStream
+    cfg = ConfigEuRoC(grid_max_feature_num=15, grid_min_feature_num=8)
+    st = SyntheticStream(cfg, seed=5, n_frames=8, motion_scale=2.5)
+    got = _run_engine(cfg, [st])
+    ref = _run_oracle(cfg, st)
+    assert len(ref[-1][0]) > 200
+    _compare(ref, got[0], 'n300')
+
+
+def test_engine_capacity_overflow_is_reported(cfg):
+    from uav_airvision_amd._native import AirvisionError
+    from uav_airvision_amd.synth import SyntheticStream
+    st = SyntheticStream(cfg, seed=0, n_frames=1)
+    with pytest.raises(AirvisionError):
+        _run_engine(cfg, [st], max_corners=500)
+
+
+def test_read_grid_state(cfg):
+    import torch
+    from uav_airvision_amd.frontend import FrontendEngine
+    from uav_airvision_amd.synth import SyntheticStream
+    st = SyntheticStream(cfg, seed=2, n_frames=1)
+    m = st.frame(0)
+    eng = FrontendEngine(cfg, 1)
+    eng.step_host(m.cam0_image, m.cam1_image, [m.timestamp])
+    (ids, uv), = eng.read_features()
+    g = eng.read_grid(0)
+    assert np.array_equal(g['ids'], ids) and g['next_feature_id'] == len(ids)
+    assert (g['lifetime'] == 1).all() and (np.diff(g['cell']) >= 0).all()
+    assert np.bincount(g['cell']).max() <= cfg.grid_min_feature_num
+    eng.close()

@@ -1,0 +1,105 @@
+"""ctypes binding of libairvision_hip.so (the C ABI declared in include/airvision.h).
+
+There is NO CPU fallback: if the shared library is missing this module raises, and every operator
+raises when the HIP call fails.  torch is imported first so that the library binds to the HIP
+runtime torch already loaded (same SONAME), i.e. one runtime / one context per process.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be loaded before libairvision_hip.so, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libairvision_hip.so')
+
+AV_MAX_LEVELS = 5
+AV_PYR_BORDER = 16
+AV_OK, AV_E_INVALID, AV_E_HIP, AV_E_CAPACITY, AV_E_NODEVICE = 0, -1, -2, -3, -4
+
+
+class AirvisionError(RuntimeError):
+    def __init__(self, code, text):
+        RuntimeError.__init__(self, 'libairvision_hip error %d: %s' % (code, text))
+        self.code = code
+
+
+class PyrLayout(C.Structure):
+    _fields_ = [('levels', C.c_int32),
+                ('w', C.c_int32 * AV_MAX_LEVELS), ('h', C.c_int32 * AV_MAX_LEVELS),
+                ('pitch', C.c_int32 * AV_MAX_LEVELS),
+                ('offset', C.c_int64 * AV_MAX_LEVELS),
+                ('bytes', C.c_int64)]
+
+
+class FrontendConfig(C.Structure):
+    _fields_ = [('width', C.c_int32), ('height', C.c_int32),
+                ('grid_row', C.c_int32), ('grid_col', C.c_int32),
+                ('grid_min_feature_num', C.c_int32), ('grid_max_feature_num', C.c_int32),
+                ('fast_threshold', C.c_int32), ('lk_win', C.c_int32), ('lk_levels', C.c_int32),
+                ('lk_max_iter', C.c_int32), ('max_corners', C.c_int32), ('reserved0', C.c_int32),
+                ('lk_eps', C.c_double), ('lk_min_eig', C.c_double), ('stereo_threshold', C.c_double),
+                ('cam0_intrinsics', C.c_double * 4), ('cam0_distortion', C.c_double * 4),
+                ('cam1_intrinsics', C.c_double * 4), ('cam1_distortion', C.c_double * 4),
+                ('R_cam0_imu', C.c_double * 9), ('R_cam1_imu', C.c_double * 9),
+                ('R0to1', C.c_double * 9), ('E', C.c_double * 9), ('norm_unit', C.c_double)]
+
+
+# name -> (restype, argtypes); the list doubles as the export check of tests/test_abi.py
+_P = C.c_void_p
+SIGNATURES = {
+    'av_last_error': (C.c_char_p, []),
+    'av_version': (C.c_char_p, []),
+    'av_device_count': (C.c_int, []),
+    'av_pyramid_layout': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(PyrLayout)]),
+    'av_pyramid_build': (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P]),
+    'av_lk_track': (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int,
+                              C.c_int, C.c_int, C.c_double, C.c_double, _P]),
+    'av_fast_detect': (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
+    'av_undistort_points': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _P, _P]),
+    'av_distort_points': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _P, _P]),
+    'av_frontend_create': (C.c_int, [C.POINTER(FrontendConfig), C.c_int, C.c_int, C.POINTER(_P)]),
+    'av_frontend_destroy': (None, [_P]),
+    'av_frontend_push_imu': (C.c_int, [_P, C.c_int, C.c_double, C.POINTER(C.c_double)]),
+    'av_frontend_step': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double), _P]),
+    'av_frontend_step_host': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double), _P]),
+    'av_frontend_max_features': (C.c_int, [_P]),
+    'av_frontend_read_features': (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
+    'av_frontend_read_grid': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64), _P]),
+    'av_frontend_read_counters': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32 * 8), _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libairvision_hip.so is not built (%s); run `python -m uav_airvision_amd.build` -- '
+                               'there is no CPU fallback' % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise AirvisionError(rc, lib().av_last_error().decode('utf-8', 'replace'))
+
+
+def current_stream():
+    """hipStream_t of torch's current stream as a void pointer."""
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def darr(a):
+    return (C.c_double * len(a))(*[float(v) for v in a])

@@ -1,0 +1,114 @@
+// av_common.h -- shared declarations of libairvision_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/airvision.h"
+
+#define AV_EXPORT extern "C" __attribute__((visibility("default")))
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void av_set_error(const char* fmt, ...);
+#define AV_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            av_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return AV_E_HIP;                                                                      \
+        }                                                                                         \
+    } while (0)
+#define AV_LAUNCH_CHECK()                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = hipGetLastError();                                                        \
+        if (e_ != hipSuccess) {                                                                   \
+            av_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return AV_E_HIP;                                                                      \
+        }                                                                                         \
+    } while (0)
+
+// ---- pyramid geometry passed by value to kernels ----------------------------------------------
+struct PyrGeom {
+    int levels;
+    int w[AV_MAX_LEVELS], h[AV_MAX_LEVELS], pitch[AV_MAX_LEVELS];
+    int off[AV_MAX_LEVELS];      // byte offset of padded (0,0) of each level (fits int)
+};
+PyrGeom av_make_geom(const av_pyr_layout& l);
+
+// ---- camera model, by value -------------------------------------------------------------------
+struct CamModel {
+    double fx, fy, cx, cy, k1, k2, p1, p2;
+};
+
+// packed FAST keypoint word: score << 19 | (2^19-1 - raster)
+#define AV_KP_RASTER_BITS 19
+#define AV_KP_RASTER_MASK ((1u << AV_KP_RASTER_BITS) - 1u)
+
+#ifdef __HIPCC__
+// cv::borderInterpolate(p, len, BORDER_REFLECT_101) for |overshoot| < len
+__device__ __forceinline__ int av_reflect101(int p, int len)
+{
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * len - 2 - p;
+    return p;
+}
+
+// cv2.undistortPoints core: 5 fixed-point iterations of the radtan inverse, then R*[x y 1].
+// Expression order follows OpenCV's cvUndistortPointsInternal; fp64, no contraction.
+__device__ __forceinline__ void av_undistort(const CamModel& c, const double* R, double u, double v, double& ox, double& oy)
+{
+    const double ifx = 1. / c.fx, ify = 1. / c.fy;
+    double x = (u - c.cx) * ifx, y = (v - c.cy) * ify;
+    const double x0 = x, y0 = y;
+#pragma unroll 1
+    for (int j = 0; j < 5; ++j) {
+        double r2 = x * x + y * y;
+        double icdist = 1. / (1 + ((0 * r2 + c.k2) * r2 + c.k1) * r2);
+        if (icdist < 0) { x = (u - c.cx) * ifx; y = (v - c.cy) * ify; break; }
+        double deltaX = 2 * c.p1 * x * y + c.p2 * (r2 + 2 * x * x);
+        double deltaY = c.p1 * (r2 + 2 * y * y) + 2 * c.p2 * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    double xx = R[0] * x + R[1] * y + R[2];
+    double yy = R[3] * x + R[4] * y + R[5];
+    double ww = 1. / (R[6] * x + R[7] * y + R[8]);
+    ox = xx * ww;
+    oy = yy * ww;
+}
+
+// cv2.projectPoints with zero rvec/tvec on (x, y, 1): radtan forward + K.
+__device__ __forceinline__ void av_distort(const CamModel& c, double x, double y, double& ou, double& ov)
+{
+    double r2 = x * x + y * y, r4 = r2 * r2;
+    double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+    double cdist = 1 + c.k1 * r2 + c.k2 * r4;
+    double xd = x * cdist + c.p1 * a1 + c.p2 * a2;
+    double yd = y * cdist + c.p1 * a3 + c.p2 * a1;
+    ou = xd * c.fx + c.cx;
+    ov = yd * c.fy + c.cy;
+}
+#endif  // __HIPCC__
+
+// ---- kernel launchers (defined in the .hip files, used by ops_api and the engine) -------------
+// pyramid.hip
+int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stride, int n_streams, int imgs_per_stream,
+                      const PyrGeom& g, uint8_t* pyr_base, int64_t stream_stride, int64_t slot_stride, int slot0, int slot1,
+                      hipStream_t st);
+
+// lk.hip
+struct LKParams {
+    int win, max_iter;
+    double eps2, min_eig;
+};
+int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride, int n_set, const PyrGeom& g,
+                 const float* prev, float* next, uint8_t* status, const int* count, int cap, int launch_pts,
+                 const LKParams& p, hipStream_t st);
+
+// fast.hip
+int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, const uint8_t* mask, int64_t mask_stride,
+                   int n_img, int w, int h, int threshold,
+                   uint32_t* kp, int* count, int cap,                               // flat output (ops API) or NULL
+                   uint32_t* cell_kp, int* cell_count, int cell_cap, int gh, int gw, int grid_col, int n_cells,   // per-cell output or NULL
+                   int* n_fast, int* overflow, int stat_stride, hipStream_t st);

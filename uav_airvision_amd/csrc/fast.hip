@@ -1,0 +1,153 @@
+// fast.hip -- FAST-9/16 corner detector with corner score and 3x3 non-max suppression (gfx950).
+//
+// Replaces cv2.FastFeatureDetector_create(threshold).detect(img, mask) (TYPE_9_16, NMS on):
+//   src/image_processing/pipeline.py:23-25 (ctor), feature_initializer.py:52, feature_adder.py:64.
+// Semantics follow OpenCV 4.x features2d/fast.cpp (FAST_t<16>) and fast_score.cpp
+// (cornerScore<16>): a pixel is a corner when 9 contiguous pixels of the 16-pixel Bresenham
+// circle are all brighter than v+t or all darker than v-t; score = the largest threshold for
+// which it stays a corner = max over the 16 arcs of min|diff| - 1; keypoints are strict maxima
+// of the score over their 8 neighbours; a 3-pixel border is never a corner; detect(img, mask)
+// drops keypoints whose mask pixel is 0 AFTER detection.  Integer-exact.
+//
+// MI355X mapping: one 256-thread workgroup per 64x16 tile; the 72x24 pixel tile and the 66x18
+// score tile live in LDS (2.9 KB), every image byte is read from HBM once (+halo), scores never
+// go to HBM.  Survivors are appended with one atomic each (a few thousand per image), either to a
+// flat list or straight into per-grid-cell candidate lists for the feature adder.
+// Bound: HBM read of the image (w*h bytes) -- the score arithmetic is ~200 VALU ops/pixel.
+#include "av_common.h"
+
+namespace {
+
+constexpr int TW = 64, TH = 16;
+constexpr int PW = TW + 8, PH = TH + 8;     // pixel tile
+constexpr int SW = TW + 2, SH = TH + 2;     // score tile
+
+struct FastArgs {
+    const uint8_t* img;
+    int64_t img_stride;
+    int img_pitch;
+    const uint8_t* mask;
+    int64_t mask_stride;
+    int w, h, threshold;
+    uint32_t* kp; int* count; int cap;
+    uint32_t* cell_kp; int* cell_count; int cell_cap, gh, gw, grid_col, n_cells;
+    int* n_fast; int* overflow; int stat_stride;
+};
+
+__device__ __forceinline__ int fast_score(const uint8_t* c, int t)
+{
+    // c points at the centre pixel inside the LDS pixel tile (row stride PW)
+    constexpr int DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    constexpr int DY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    const int v = c[0];
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = v - (int)c[DY[k] * PW + DX[k]];
+    // sliding min / max over circular windows of 9
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { lo4[i] = min(lo2[i], lo2[(i + 2) & 15]); hi4[i] = max(hi2[i], hi2[(i + 2) & 15]); }
+    int A = -256, Bm = 256;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int lo9 = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
+        int hi9 = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
+        A = max(A, lo9);        // best arc of "centre brighter than ring by at least"
+        Bm = min(Bm, hi9);      // best arc of "centre darker than ring by at least" (negated)
+    }
+    const int m = max(A, -Bm);
+    return m > t ? m - 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
+{
+    __shared__ uint8_t pix[PH * PW];
+    __shared__ uint8_t sc[SH * SW];
+    const int img_i = blockIdx.z;
+    const uint8_t* img = a.img + img_i * a.img_stride;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < PH * PW; i += 256) {
+        int r = i / PW, c = i - r * PW;
+        int y = min(max(y0 - 4 + r, 0), a.h - 1), x = min(max(x0 - 4 + c, 0), a.w - 1);
+        pix[i] = img[(size_t)y * a.img_pitch + x];
+    }
+    __syncthreads();
+    for (int i = tid; i < SH * SW; i += 256) {
+        int r = i / SW, c = i - r * SW;
+        int y = y0 - 1 + r, x = x0 - 1 + c;
+        int s = 0;
+        if (x >= 3 && x < a.w - 3 && y >= 3 && y < a.h - 3) s = fast_score(&pix[(r + 3) * PW + (c + 3)], a.threshold);
+        sc[i] = (uint8_t)s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (TW * TH) / 256; ++k) {
+        int i = tid + 256 * k;
+        int r = i / TW, c = i - r * TW;
+        int x = x0 + c, y = y0 + r;
+        const uint8_t* p = &sc[(r + 1) * SW + (c + 1)];
+        int s = p[0];
+        bool keep = s > 0 && x < a.w && y < a.h &&
+                    s > p[-1] && s > p[1] && s > p[-SW - 1] && s > p[-SW] && s > p[-SW + 1] &&
+                    s > p[SW - 1] && s > p[SW] && s > p[SW + 1];
+        if (keep && a.mask) keep = a.mask[img_i * a.mask_stride + (size_t)y * a.w + x] != 0;
+        if (keep) {
+            const uint32_t word = ((uint32_t)s << AV_KP_RASTER_BITS) | (AV_KP_RASTER_MASK - (uint32_t)(y * a.w + x));
+            if (a.n_fast) atomicAdd(&a.n_fast[img_i * a.stat_stride], 1);
+            if (a.kp) {
+                int idx = atomicAdd(&a.count[img_i], 1);
+                if (idx < a.cap) a.kp[(size_t)img_i * a.cap + idx] = word;
+                else if (a.overflow) atomicOr(&a.overflow[img_i * a.stat_stride], 1);
+            }
+            if (a.cell_kp) {
+                int cell = (y / a.gh) * a.grid_col + (x / a.gw);
+                int idx = atomicAdd(&a.cell_count[img_i * a.n_cells + cell], 1);
+                if (idx < a.cell_cap) a.cell_kp[((size_t)img_i * a.n_cells + cell) * a.cell_cap + idx] = word;
+                else if (a.overflow) atomicOr(&a.overflow[img_i * a.stat_stride], 2);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, const uint8_t* mask, int64_t mask_stride,
+                   int n_img, int w, int h, int threshold,
+                   uint32_t* kp, int* count, int cap,
+                   uint32_t* cell_kp, int* cell_count, int cell_cap, int gh, int gw, int grid_col, int n_cells,
+                   int* n_fast, int* overflow, int stat_stride, hipStream_t st)
+{
+    if (n_img <= 0) return AV_OK;
+    if ((int64_t)w * h > (int64_t)(AV_KP_RASTER_MASK + 1)) {
+        av_set_error("av_fast_detect: image %dx%d exceeds 2^19 pixels", w, h);
+        return AV_E_INVALID;
+    }
+    FastArgs a;
+    a.img = img; a.img_stride = img_stride; a.img_pitch = img_pitch; a.mask = mask; a.mask_stride = mask_stride;
+    a.w = w; a.h = h; a.threshold = threshold;
+    a.kp = kp; a.count = count; a.cap = cap;
+    a.cell_kp = cell_kp; a.cell_count = cell_count; a.cell_cap = cell_cap; a.gh = gh; a.gw = gw;
+    a.grid_col = grid_col; a.n_cells = n_cells; a.n_fast = n_fast; a.overflow = overflow; a.stat_stride = stat_stride;
+    dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, n_img);
+    hipLaunchKernelGGL(fast_kernel, grid, dim3(256), 0, st, a);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+AV_EXPORT int av_fast_detect(const uint8_t* img_dev, int64_t img_stride, const uint8_t* mask_dev, int64_t mask_stride,
+                             int n_img, int w, int h, int threshold, uint32_t* kp_dev, int32_t* count_dev, int cap,
+                             void* stream)
+{
+    if (!img_dev || !kp_dev || !count_dev || cap <= 0 || n_img < 0 || w < 7 || h < 7 || img_stride < (int64_t)w * h) {
+        av_set_error("av_fast_detect: bad arguments");
+        return AV_E_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    AV_HIP(hipMemsetAsync(count_dev, 0, sizeof(int) * (size_t)n_img, st));
+    return av_launch_fast(img_dev, img_stride, w, mask_dev, mask_stride, n_img, w, h, threshold, kp_dev, count_dev, cap,
+                          nullptr, nullptr, 0, 1, 1, 1, 1, nullptr, nullptr, 0, st);
+}

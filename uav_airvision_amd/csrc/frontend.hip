@@ -1,0 +1,832 @@
+// frontend.hip -- the image front-end as a device-resident engine over S independent stereo streams.
+//
+// Reference being replaced (all under src/image_processing/):
+//   pipeline.py:14-150            ImageProcessingPipeline.{__init__, imu_callback, stereo_callback}
+//   imu_processor.py:22-67        IMU buffer, mean-gyro rotation prediction
+//   feature_initializer.py:45-85  first frame: FAST -> stereo match all -> top-3/cell -> ids
+//   feature_tracker.py:74-177     temporal LK, bounds mask, stereo re-match, re-bin, lifetime+1
+//   stereo_matcher.py:33-115      predict -> LK fwd -> LK bwd -> gates (err<3, |dy|<20, bounds, epipolar)
+//   feature_adder.py:52-108       7x7 mask, FAST(mask), top-5/cell, stereo match, top-3/cell, ids
+//   feature_pruner.py:8-19        per cell keep top-5 by lifetime (stable)
+//   feature_publisher.py:90-121   undistort to normalised coords -> feature_msg
+//
+// The reference runs one stream, one frame at a time, with Python lists of FeatureMetaData.  Here
+// the per-stream state (feature grid, ids, three padded pyramids, FAST mask) lives in HBM for all S
+// streams; one call to av_frontend_step enqueues ~15 batched kernels (grid.y or block = stream) and
+// never synchronises with the host.  Frames of one stream are a dependent chain (LK at t needs the
+// points of t-1), streams are independent, so S is the parallel axis that fills 256 CUs.
+//
+// Order-sensitive list semantics of the reference are reproduced exactly:
+//   * `select(...)` compactions keep order  -> ballot/popcount ordered compaction per stream
+//   * Python's stable `sorted(key=response/lifetime, reverse=True)` -> explicit (key, insertion index)
+//     total orders: FAST candidates by (score desc, raster asc), pruning by (lifetime desc, insertion)
+//   * ids are handed out cell-major, response-descending inside a cell
+//   * the 7x7 FAST mask follows numpy slice semantics (no masking when x<3 or y<3)
+#include <math.h>
+
+#include <deque>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "av_common.h"
+
+namespace {
+
+constexpr int CNT_BEFORE = 0, CNT_TRACKED = 1, CNT_MATCHED = 2, CNT_FAST = 3, CNT_CAND = 4, CNT_NEW = 5, CNT_PUB = 6, CNT_OVF = 7;
+constexpr int NCNT = 8;
+constexpr unsigned long long LIFE_MAX = 0xFFFFFFull;
+
+// everything the glue kernels need, by value
+struct FeDev {
+    int S, w, h, C, grid_row, grid_col, gh, gw, gmin, gmax;
+    int MAXF;        // capacity of a published grid  = C * gmax
+    int NT;          // capacity of tracker work lists = MAXF
+    int CC;          // capacity of the candidate list = max(max_corners, C * gmax)
+    int cell_cap;    // capacity of one cell's FAST list
+    int NSORT;       // pow2 >= C * (gmax + gmin)
+    CamModel cam0, cam1;
+    double R0to1[9], E[9], I3[9];
+    double epi_thr;
+    // published grid, double buffered (index = parity)
+    long long* feat_id[2]; int* feat_life[2]; float* feat_p0[2]; float* feat_p1[2]; int* feat_cell[2]; int* n_feat[2];
+    long long* next_id; int* first_frame;
+    const double* Hmat;                                   // [S][9]
+    // temporal tracking
+    float* trk_prev; float* trk_next; uint8_t* trk_status; int* trk_count;
+    // survivors of temporal tracking, stereo-matched
+    int* sv_src; float* sv_p0; float* sv_init; float* sv_p1; uint8_t* sv_st; float* sv_back; uint8_t* sv_st2; int* sv_count;
+    // curr_features after the tracker (insertion order)
+    long long* cur_id; int* cur_life; float* cur_p0; float* cur_p1; int* cur_cell; int* cur_count;
+    // FAST per-cell lists + mask
+    uint32_t* cell_kp; int* cell_count; uint8_t* mask;
+    // candidates for new features
+    uint32_t* cand_key; float* cand_p0; float* cand_init; float* cand_p1; uint8_t* cand_st; float* cand_back; uint8_t* cand_st2;
+    uint8_t* cand_inl; int* cand_off; int* cand_count;
+    // output
+    long long* out_ids; double* out_uv; int* out_n;
+    int* counters;
+};
+
+__device__ __forceinline__ int cell_of(const FeDev& d, float x, float y)
+{
+    // int(pt[1] / grid_h) * grid_col + int(pt[0] / grid_w)  (feature_tracker.py:144-146); float32 division
+    return (int)(y / (float)d.gh) * d.grid_col + (int)(x / (float)d.gw);
+}
+
+// ordered compaction position inside a 256-thread block; `base` is a running total in registers
+__device__ __forceinline__ int block_ordered_pos(bool flag, int& base, int* lds4)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long b = __ballot(flag);
+    int lane_prefix = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) lds4[wv] = __popcll(b);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { int c = lds4[i]; if (i < wv) off += c; tot += c; }
+    int pos = base + off + lane_prefix;
+    base += tot;
+    __syncthreads();
+    return pos;
+}
+
+// stereo_matcher.py:47-61: initial guess in cam1 = distort(undistort(p, R0to1)) with the cam0 model
+__device__ __forceinline__ void stereo_init(const FeDev& d, float x, float y, float& ox, float& oy)
+{
+    double ux, uy;
+    av_undistort(d.cam0, d.R0to1, (double)x, (double)y, ux, uy);
+    float fx = (float)ux, fy = (float)uy;                      // undistortPoints output is float32
+    double px, py;
+    av_distort(d.cam0, (double)fx, (double)fy, px, py);
+    ox = (float)px; oy = (float)py;                            // projectPoints output is float32
+}
+
+// stereo_matcher.py:75-113
+__device__ __forceinline__ bool stereo_gate(const FeDev& d, float p0x, float p0y, float inx, float iny, float p1x, float p1y,
+                                            uint8_t st, float bx, float by)
+{
+    (void)inx;
+    if (!st) return false;
+    float ex = p0x - bx, ey = p0y - by;
+    float err = sqrtf(ex * ex + ey * ey);
+    if (!(err < 3.f)) return false;
+    float disp = fabsf(iny - p1y);
+    if (!(disp < 20.f)) return false;
+    if (p1x < 0 || p1x >= (float)d.w || p1y < 0 || p1y >= (float)d.h) return false;
+    double ax, ay, bxx, byy;
+    av_undistort(d.cam0, d.I3, (double)p0x, (double)p0y, ax, ay);
+    av_undistort(d.cam0, d.I3, (double)p1x, (double)p1y, bxx, byy);
+    double u0x = (double)(float)ax, u0y = (double)(float)ay, u1x = (double)(float)bxx;
+    double l0 = (d.E[0] * u0x + d.E[1] * u0y) + d.E[2] * 1.0;
+    double l1 = (d.E[3] * u0x + d.E[4] * u0y) + d.E[5] * 1.0;
+    double err_epi = fabs(u1x * l0) / sqrt(l0 * l0 + l1 * l1);
+    if (err_epi > d.epi_thr) return false;
+    return true;
+}
+
+// ---- G1: predicted positions for temporal tracking (feature_tracker.py:86-101,159-177) --------
+__global__ __launch_bounds__(256) void track_prepare_kernel(FeDev d, int par)
+{
+    const int s = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int n = d.n_feat[par][s];
+    if (i == 0) { d.trk_count[s] = n; d.counters[s * NCNT + CNT_BEFORE] = n; }
+    if (i >= n) return;
+    const size_t k = (size_t)s * d.MAXF + i, t = (size_t)s * d.NT + i;
+    float x = d.feat_p0[par][2 * k], y = d.feat_p0[par][2 * k + 1];
+    const double* H = d.Hmat + s * 9;
+    double h0 = (H[0] * (double)x + H[1] * (double)y) + H[2] * 1.0;
+    double h1 = (H[3] * (double)x + H[4] * (double)y) + H[5] * 1.0;
+    double h2 = (H[6] * (double)x + H[7] * (double)y) + H[8] * 1.0;
+    d.trk_prev[2 * t] = x; d.trk_prev[2 * t + 1] = y;
+    d.trk_next[2 * t] = (float)(h0 / h2); d.trk_next[2 * t + 1] = (float)(h1 / h2);
+}
+
+// ---- G2: bounds mask + ordered compaction + stereo initial guess (feature_tracker.py:110-126) --
+__global__ __launch_bounds__(256) void track_gate_kernel(FeDev d)
+{
+    __shared__ int lds4[4];
+    const int s = blockIdx.x;
+    const int n = d.trk_count[s];
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        const size_t t = (size_t)s * d.NT + i;
+        bool keep = false; float x = 0, y = 0;
+        if (i < n) {
+            x = d.trk_next[2 * t]; y = d.trk_next[2 * t + 1];
+            keep = d.trk_status[t] != 0 && !(x < 0 || x > (float)(d.w - 1) || y < 0 || y > (float)(d.h - 1));
+        }
+        int pos = block_ordered_pos(keep, base, lds4);
+        if (keep) {
+            const size_t o = (size_t)s * d.NT + pos;
+            d.sv_src[o] = i;
+            d.sv_p0[2 * o] = x; d.sv_p0[2 * o + 1] = y;
+            float ix, iy;
+            stereo_init(d, x, y, ix, iy);
+            d.sv_init[2 * o] = ix; d.sv_init[2 * o + 1] = iy;
+            d.sv_p1[2 * o] = ix; d.sv_p1[2 * o + 1] = iy;
+            d.sv_back[2 * o] = x; d.sv_back[2 * o + 1] = y;
+        }
+    }
+    if (threadIdx.x == 0) { d.sv_count[s] = base; d.counters[s * NCNT + CNT_TRACKED] = base; }
+}
+
+// 7x7 box of the FAST mask with numpy slice semantics (feature_adder.py:59-62)
+__device__ __forceinline__ void mask_box(const FeDev& d, uint8_t* m, float px, float py, int j, uint8_t val)
+{
+    int fx = (int)px, fy = (int)py;
+    if (fx < 3 || fy < 3) return;                 // negative slice start => empty slice
+    int yy = fy - 3 + j / 7, xx = fx - 3 + j % 7;
+    if (yy < d.h && xx < d.w) m[(size_t)yy * d.w + xx] = val;
+}
+
+// ---- G3: stereo gate of the survivors, re-bin into curr_features, set FAST mask ----------------
+__global__ __launch_bounds__(256) void rebin_kernel(FeDev d, int par)
+{
+    __shared__ int lds4[4];
+    const int s = blockIdx.x;
+    const int n = d.sv_count[s];
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        const size_t t = (size_t)s * d.NT + i;
+        bool keep = false;
+        if (i < n)
+            keep = stereo_gate(d, d.sv_p0[2 * t], d.sv_p0[2 * t + 1], d.sv_init[2 * t], d.sv_init[2 * t + 1],
+                               d.sv_p1[2 * t], d.sv_p1[2 * t + 1], d.sv_st[t], d.sv_back[2 * t], d.sv_back[2 * t + 1]);
+        int pos = block_ordered_pos(keep, base, lds4);
+        if (keep) {
+            const size_t o = (size_t)s * d.NT + pos;
+            const size_t src = (size_t)s * d.MAXF + d.sv_src[t];
+            d.cur_id[o] = d.feat_id[par][src];
+            d.cur_life[o] = d.feat_life[par][src] + 1;
+            float x = d.sv_p0[2 * t], y = d.sv_p0[2 * t + 1];
+            d.cur_p0[2 * o] = x; d.cur_p0[2 * o + 1] = y;
+            d.cur_p1[2 * o] = d.sv_p1[2 * t]; d.cur_p1[2 * o + 1] = d.sv_p1[2 * t + 1];
+            d.cur_cell[o] = cell_of(d, x, y);
+        }
+    }
+    if (threadIdx.x == 0) { d.cur_count[s] = base; d.counters[s * NCNT + CNT_MATCHED] = base; }
+    __syncthreads();
+    uint8_t* m = d.mask + (size_t)s * d.w * d.h;
+    for (int q = threadIdx.x; q < base * 49; q += 256) {
+        int f = q / 49, j = q - f * 49;
+        const size_t o = (size_t)s * d.NT + f;
+        mask_box(d, m, d.cur_p0[2 * o], d.cur_p0[2 * o + 1], j, 0);
+    }
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        unsigned long long o = __shfl_xor(v, m, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// ---- G5: per-cell top-grid_max FAST candidates (feature_adder.py:66-80) or all of them on the
+//          first frame (feature_initializer.py:52-55), plus their stereo initial guess ----------
+__global__ __launch_bounds__(256) void select_kernel(FeDev d)
+{
+    extern __shared__ int sm[];
+    int* cnt = sm;               // [C]
+    int* off = sm + d.C;         // [C+1]
+    const int s = blockIdx.x;
+    const bool first = d.first_frame[s] != 0;
+    for (int c = threadIdx.x; c < d.C; c += 256) {
+        int n = min(d.cell_count[s * d.C + c], d.cell_cap);
+        cnt[c] = first ? n : min(n, d.gmax);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int c = 0; c < d.C; ++c) {
+            off[c] = acc;
+            int take = cnt[c];
+            if (acc + take > d.CC) { take = d.CC - acc; atomicOr(&d.counters[s * NCNT + CNT_OVF], 4); }
+            cnt[c] = take;
+            acc += take;
+        }
+        off[d.C] = acc;
+        d.cand_count[s] = acc;
+        d.counters[s * NCNT + CNT_CAND] = acc;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c <= d.C; c += 256) d.cand_off[s * (d.C + 1) + c] = off[c];
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c = wv; c < d.C; c += 4) {
+        const uint32_t* list = d.cell_kp + ((size_t)s * d.C + c) * d.cell_cap;
+        const int n = min(d.cell_count[s * d.C + c], d.cell_cap);
+        const int take = cnt[c];
+        uint32_t* dst = d.cand_key + (size_t)s * d.CC + off[c];
+        if (first) {
+            for (int i = lane; i < take; i += 64) dst[i] = list[i];
+        } else {
+            uint32_t last = 0xFFFFFFFFu;
+            for (int r = 0; r < take; ++r) {
+                uint32_t best = 0;
+                for (int i = lane; i < n; i += 64) { uint32_t k = list[i]; if (k < last && k > best) best = k; }
+                best = (uint32_t)wave_max_u64(best);
+                if (lane == 0) dst[r] = best;
+                last = best;
+            }
+        }
+    }
+    __syncthreads();
+    const int total = off[d.C];
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const size_t o = (size_t)s * d.CC + i;
+        uint32_t raster = AV_KP_RASTER_MASK - (d.cand_key[o] & AV_KP_RASTER_MASK);
+        float y = (float)(raster / (uint32_t)d.w), x = (float)(raster % (uint32_t)d.w);
+        d.cand_p0[2 * o] = x; d.cand_p0[2 * o + 1] = y;
+        float ix, iy;
+        stereo_init(d, x, y, ix, iy);
+        d.cand_init[2 * o] = ix; d.cand_init[2 * o + 1] = iy;
+        d.cand_p1[2 * o] = ix; d.cand_p1[2 * o + 1] = iy;
+        d.cand_back[2 * o] = x; d.cand_back[2 * o + 1] = y;
+    }
+}
+
+__device__ __forceinline__ void bitonic_sort_u64(unsigned long long* k, int n)
+{
+    for (int size = 2; size <= n; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (n >> 1); t += 256) {
+                int lo = 2 * t - (t & (stride - 1));
+                int hi = lo + stride;
+                bool up = (lo & size) == 0;
+                unsigned long long a = k[lo], b = k[hi];
+                if ((a > b) == up) { k[lo] = b; k[hi] = a; }
+            }
+        }
+    __syncthreads();
+}
+
+// ---- G7: new-feature selection + ids, prune, publish, mask restore ------------------------------
+//  feature_adder.py:82-108 / feature_initializer.py:57-85, feature_pruner.py:8-19,
+//  feature_publisher.py:90-121, pipeline.py:145-148
+__global__ __launch_bounds__(256) void finalize_kernel(FeDev d, int par)
+{
+    extern __shared__ unsigned long long smem64[];
+    unsigned long long* keys = smem64;                               // [NSORT]
+    int* ism = reinterpret_cast<int*>(keys + d.NSORT);
+    int* sel = ism;                   ism += d.C * d.gmin;           // candidate index of selection (c, r)
+    int* sel_n = ism;                 ism += d.C;
+    int* sel_pre = ism;               ism += d.C + 1;
+    int* trk_n = ism;                 ism += d.C;                    // tracked features per cell
+    int* cell_start = ism;            ism += d.C + 1;                // start of each cell in the sorted order
+    int* out_start = ism;             ism += d.C + 1;                // start of each cell in the pruned grid
+    int* new_cand = ism;              ism += d.C * d.gmin;           // insertion rank -> candidate index
+    int* flags = ism;                 ism += 4;                      // [0] has_new among published
+
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int T = d.cur_count[s];
+    const int ncand = d.cand_count[s];
+    const int* coff = d.cand_off + s * (d.C + 1);
+    const int nxt = par ^ 1;
+
+    // A. stereo gate of every candidate
+    for (int i = threadIdx.x; i < ncand; i += 256) {
+        const size_t o = (size_t)s * d.CC + i;
+        d.cand_inl[o] = stereo_gate(d, d.cand_p0[2 * o], d.cand_p0[2 * o + 1], d.cand_init[2 * o], d.cand_init[2 * o + 1],
+                                    d.cand_p1[2 * o], d.cand_p1[2 * o + 1], d.cand_st[o], d.cand_back[2 * o], d.cand_back[2 * o + 1]) ? 1 : 0;
+    }
+    for (int c = threadIdx.x; c < d.C; c += 256) trk_n[c] = 0;
+    if (threadIdx.x == 0) flags[0] = 0;
+    __syncthreads();
+
+    // B. per cell: top grid_min inliers by (response desc, raster asc)
+    for (int c = wv; c < d.C; c += 4) {
+        const int b = coff[c], e = coff[c + 1];
+        uint32_t last = 0xFFFFFFFFu;
+        int r = 0;
+        for (; r < d.gmin; ++r) {
+            unsigned long long best = 0;
+            for (int i = b + lane; i < e; i += 64) {
+                const size_t o = (size_t)s * d.CC + i;
+                uint32_t k = d.cand_key[o];
+                if (d.cand_inl[o] && k < last) {
+                    unsigned long long v = ((unsigned long long)k << 32) | (uint32_t)i;
+                    if (v > best) best = v;
+                }
+            }
+            best = wave_max_u64(best);
+            if (best == 0) break;
+            if (lane == 0) sel[c * d.gmin + r] = (int)(best & 0xFFFFFFFFu);
+            last = (uint32_t)(best >> 32);
+        }
+        if (lane == 0) sel_n[c] = r;
+    }
+    // D. tracked features per cell
+    for (int i = threadIdx.x; i < T; i += 256) atomicAdd(&trk_n[d.cur_cell[(size_t)s * d.NT + i]], 1);
+    __syncthreads();
+
+    // C. prefixes (C <= 256 cells: serial is fine)
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0, o = 0;
+        for (int c = 0; c < d.C; ++c) {
+            sel_pre[c] = a; cell_start[c] = b; out_start[c] = o;
+            int nc = trk_n[c] + sel_n[c];
+            a += sel_n[c]; b += nc; o += min(nc, d.gmax);
+        }
+        sel_pre[d.C] = a; cell_start[d.C] = b; out_start[d.C] = o;
+    }
+    __syncthreads();
+    const int n_new = sel_pre[d.C];
+    const int M = T + n_new;
+
+    // E. sort keys: cell | (lifetime key when the cell will be pruned) | insertion index
+    for (int j = threadIdx.x; j < d.NSORT; j += 256) keys[j] = ~0ull;
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += 256) {
+        const size_t o = (size_t)s * d.NT + i;
+        const int c = d.cur_cell[o];
+        const bool pruned = trk_n[c] + sel_n[c] > d.gmax;
+        unsigned long long lk = pruned ? (LIFE_MAX - (unsigned long long)d.cur_life[o]) : 0ull;
+        keys[i] = ((unsigned long long)c << 48) | (lk << 24) | (unsigned long long)i;
+    }
+    for (int q = threadIdx.x; q < d.C * d.gmin; q += 256) {
+        const int c = q / d.gmin, r = q - c * d.gmin;
+        if (r < sel_n[c]) {
+            const int ins = T + sel_pre[c] + r;
+            new_cand[ins - T] = sel[q];
+            const bool pruned = trk_n[c] + sel_n[c] > d.gmax;
+            unsigned long long lk = pruned ? (LIFE_MAX - 1ull) : 0ull;
+            keys[ins] = ((unsigned long long)c << 48) | (lk << 24) | (unsigned long long)ins;
+        }
+    }
+    bitonic_sort_u64(keys, d.NSORT);
+
+    // G. pruned grid of this frame, cell-major
+    const long long id0 = d.next_id[s];
+    for (int j = threadIdx.x; j < M; j += 256) {
+        const unsigned long long k = keys[j];
+        const int c = (int)(k >> 48), ins = (int)(k & 0xFFFFFFull);
+        const int rank = j - cell_start[c];
+        if (rank >= d.gmax) continue;
+        const size_t o = (size_t)s * d.MAXF + out_start[c] + rank;
+        if (ins < T) {
+            const size_t t = (size_t)s * d.NT + ins;
+            d.feat_id[nxt][o] = d.cur_id[t];
+            d.feat_life[nxt][o] = d.cur_life[t];
+            d.feat_p0[nxt][2 * o] = d.cur_p0[2 * t]; d.feat_p0[nxt][2 * o + 1] = d.cur_p0[2 * t + 1];
+            d.feat_p1[nxt][2 * o] = d.cur_p1[2 * t]; d.feat_p1[nxt][2 * o + 1] = d.cur_p1[2 * t + 1];
+        } else {
+            const size_t q = (size_t)s * d.CC + new_cand[ins - T];
+            d.feat_id[nxt][o] = id0 + (ins - T);
+            d.feat_life[nxt][o] = 1;
+            d.feat_p0[nxt][2 * o] = d.cand_p0[2 * q]; d.feat_p0[nxt][2 * o + 1] = d.cand_p0[2 * q + 1];
+            d.feat_p1[nxt][2 * o] = d.cand_p1[2 * q]; d.feat_p1[nxt][2 * o + 1] = d.cand_p1[2 * q + 1];
+            flags[0] = 1;                                   // benign race: all writers store 1
+        }
+        d.feat_cell[nxt][o] = c;
+    }
+    __syncthreads();
+    const int n_out = out_start[d.C];
+    // feature_publisher.py:97-107 dtype rule: cam0 coordinates stay float64 iff any
+    // published cam0 point is a FAST tuple (= a feature created this frame); cam1 is always float32.
+    const bool f64 = flags[0] != 0;
+    for (int j = threadIdx.x; j < n_out; j += 256) {
+        const size_t o = (size_t)s * d.MAXF + j;
+        double u0, v0, u1, v1;
+        av_undistort(d.cam0, d.I3, (double)d.feat_p0[nxt][2 * o], (double)d.feat_p0[nxt][2 * o + 1], u0, v0);
+        av_undistort(d.cam1, d.I3, (double)d.feat_p1[nxt][2 * o], (double)d.feat_p1[nxt][2 * o + 1], u1, v1);
+        if (!f64) { u0 = (double)(float)u0; v0 = (double)(float)v0; }
+        d.out_ids[o] = d.feat_id[nxt][o];
+        d.out_uv[4 * o] = u0; d.out_uv[4 * o + 1] = v0;
+        d.out_uv[4 * o + 2] = (double)(float)u1; d.out_uv[4 * o + 3] = (double)(float)v1;
+    }
+    // restore the FAST mask to all ones
+    uint8_t* m = d.mask + (size_t)s * d.w * d.h;
+    for (int q = threadIdx.x; q < T * 49; q += 256) {
+        int f = q / 49, j = q - f * 49;
+        const size_t o = (size_t)s * d.NT + f;
+        mask_box(d, m, d.cur_p0[2 * o], d.cur_p0[2 * o + 1], j, 1);
+    }
+    if (threadIdx.x == 0) {
+        d.n_feat[nxt][s] = n_out;
+        d.out_n[s] = n_out;
+        d.next_id[s] = id0 + n_new;
+        d.first_frame[s] = 0;
+        d.counters[s * NCNT + CNT_NEW] = n_new;
+        d.counters[s * NCNT + CNT_PUB] = n_out;
+    }
+}
+
+// ---- host-side engine ---------------------------------------------------------------------------
+struct ImuSample { double t; double w[3]; };
+
+struct StreamHost {
+    std::deque<ImuSample> imu;
+    std::mutex mu;
+    double t_prev = 0.0;
+    bool first = true;
+};
+
+inline void mat3_mul(const double* A, const double* B, double* o)
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) o[i * 3 + j] = (A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j]) + A[i * 3 + 2] * B[2 * 3 + j];
+}
+
+// cv::Rodrigues (vector -> matrix), as imu_processor.py:63-64 uses it
+inline void rodrigues(const double* r, double* R)
+{
+    double theta = sqrt((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+    if (theta < 2.220446049250313e-16) { for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0; return; }
+    double c = cos(theta), s = sin(theta), c1 = 1. - c, it = 1. / theta;
+    double x = r[0] * it, y = r[1] * it, z = r[2] * it;
+    double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
+    double rx[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+    for (int i = 0; i < 9; ++i) R[i] = (c * ((i % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[i]) + s * rx[i];
+}
+
+}  // namespace
+
+struct av_frontend {
+    av_frontend_config cfg;
+    int device = 0;
+    FeDev d;
+    av_pyr_layout lay;
+    PyrGeom geom;
+    LKParams lk;
+    uint8_t* pyr = nullptr;            // [S][3][lay.bytes]
+    uint8_t* stage_img = nullptr;      // [2][S][w*h] for step_host
+    void* zero_region = nullptr; size_t zero_bytes = 0;
+    std::vector<void*> allocs;
+    double* dH = nullptr;
+    double* hH[8] = {nullptr}; hipEvent_t hH_ev[8]; int hH_slot = 0;
+    int parity = 0;                    // index of the "prev" grid buffer; cam0 prev pyramid slot
+    std::vector<StreamHost> streams;
+    bool any_first = true;
+    std::vector<long long> h_ids; std::vector<double> h_uv; std::vector<int> h_n;
+
+    explicit av_frontend(int S) : streams(S) {}
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(av_frontend* fe, T** p, size_t count, int fill = 0)
+{
+    void* q = nullptr;
+    AV_HIP(hipMalloc(&q, count * sizeof(T) + 256));
+    AV_HIP(hipMemset(q, fill, count * sizeof(T) + 256));
+    fe->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return AV_OK;
+}
+
+int integrate_imu(av_frontend* fe, int s, double t_curr, double* H)
+{
+    // imu_processor.py:28-67 + feature_tracker.py:166-171
+    StreamHost& sh = fe->streams[s];
+    const av_frontend_config& c = fe->cfg;
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    {
+        std::lock_guard<std::mutex> g(sh.mu);
+        int ib = -1, ie = -1;
+        const int n = (int)sh.imu.size();
+        for (int i = 0; i < n; ++i) if (sh.imu[i].t >= sh.t_prev - 0.01) { ib = i; break; }
+        for (int i = 0; i < n; ++i) if (sh.imu[i].t >= t_curr - 0.004) { ie = i; break; }
+        if (ib >= 0 && ie >= 0) {
+            double m[3] = {0, 0, 0};
+            for (int i = ib; i < ie; ++i) { m[0] += sh.imu[i].w[0]; m[1] += sh.imu[i].w[1]; m[2] += sh.imu[i].w[2]; }
+            int cnt = ie - ib;
+            if (cnt > 0) { m[0] /= cnt; m[1] /= cnt; m[2] /= cnt; }
+            // cam0_mean = R_cam0_imu.T @ mean
+            const double* Rc = c.R_cam0_imu;
+            double cm[3];
+            for (int i = 0; i < 3; ++i) cm[i] = (Rc[0 * 3 + i] * m[0] + Rc[1 * 3 + i] * m[1]) + Rc[2 * 3 + i] * m[2];
+            double dt = t_curr - sh.t_prev;
+            double rv[3] = {cm[0] * dt, cm[1] * dt, cm[2] * dt};
+            double Rr[9];
+            rodrigues(rv, Rr);
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i * 3 + j] = Rr[j * 3 + i];      // .T
+            sh.imu.erase(sh.imu.begin(), sh.imu.begin() + ie);
+        }
+    }
+    const double fx = c.cam0_intrinsics[0], fy = c.cam0_intrinsics[1], cx = c.cam0_intrinsics[2], cy = c.cam0_intrinsics[3];
+    double K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1};
+    double Ki[9] = {1. / fx, 0, -cx / fx, 0, 1. / fy, -cy / fy, 0, 0, 1};
+    double KR[9];
+    mat3_mul(K, R, KR);
+    mat3_mul(KR, Ki, H);
+    return AV_OK;
+}
+
+int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t img_stride, const double* ts, hipStream_t st)
+{
+    FeDev& d = fe->d;
+    const int S = d.S;
+    AV_HIP(hipSetDevice(fe->device));
+    // host: IMU rotation prediction -> homographies
+    const int slot = fe->hH_slot;
+    fe->hH_slot = (slot + 1) & 7;
+    AV_HIP(hipEventSynchronize(fe->hH_ev[slot]));
+    double* hH = fe->hH[slot];
+    bool any_first = false;
+    for (int s = 0; s < S; ++s) {
+        StreamHost& sh = fe->streams[s];
+        if (sh.first) {
+            any_first = true;
+            for (int i = 0; i < 9; ++i) hH[s * 9 + i] = (i % 4 == 0) ? 1.0 : 0.0;
+        } else {
+            integrate_imu(fe, s, ts[s], hH + s * 9);
+        }
+        sh.t_prev = ts[s];
+        sh.first = false;
+    }
+    AV_HIP(hipMemcpyAsync(fe->dH, hH, sizeof(double) * 9 * S, hipMemcpyHostToDevice, st));
+    AV_HIP(hipEventRecord(fe->hH_ev[slot], st));
+    AV_HIP(hipMemsetAsync(fe->zero_region, 0, fe->zero_bytes, st));
+
+    const int par = fe->parity;              // prev grid buffer / prev cam0 pyramid slot
+    const int cur0 = par ^ 1;                // curr cam0 pyramid slot (0/1), cam1 pyramid is slot 2
+    const int64_t sstride = 3 * fe->lay.bytes, slotb = fe->lay.bytes;
+    int rc;
+    if ((rc = av_launch_pyramid(img0, img1, img_stride, S, 2, fe->geom, fe->pyr, sstride, slotb, cur0, 2, st))) return rc;
+
+    const uint8_t* P_prev0 = fe->pyr + par * slotb;
+    const uint8_t* P_cur0 = fe->pyr + cur0 * slotb;
+    const uint8_t* P_cur1 = fe->pyr + 2 * slotb;
+
+    hipLaunchKernelGGL(track_prepare_kernel, dim3((d.NT + 255) / 256, S), dim3(256), 0, st, d, par);
+    AV_LAUNCH_CHECK();
+    if ((rc = av_launch_lk(P_prev0, P_cur0, sstride, S, fe->geom, d.trk_prev, d.trk_next, d.trk_status, d.trk_count, d.NT, d.NT, fe->lk, st))) return rc;
+    hipLaunchKernelGGL(track_gate_kernel, dim3(S), dim3(256), 0, st, d);
+    AV_LAUNCH_CHECK();
+    if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.sv_p0, d.sv_p1, d.sv_st, d.sv_count, d.NT, d.NT, fe->lk, st))) return rc;
+    if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.sv_p1, d.sv_back, d.sv_st2, d.sv_count, d.NT, d.NT, fe->lk, st))) return rc;
+    hipLaunchKernelGGL(rebin_kernel, dim3(S), dim3(256), 0, st, d, par);
+    AV_LAUNCH_CHECK();
+    if ((rc = av_launch_fast(img0, img_stride, d.w, d.mask, (int64_t)d.w * d.h, S, d.w, d.h, fe->cfg.fast_threshold,
+                             nullptr, nullptr, 0, d.cell_kp, d.cell_count, d.cell_cap, d.gh, d.gw, d.grid_col, d.C,
+                             d.counters + CNT_FAST, d.counters + CNT_OVF, NCNT, st))) return rc;
+    hipLaunchKernelGGL(select_kernel, dim3(S), dim3(256), sizeof(int) * (2 * d.C + 1), st, d);
+    AV_LAUNCH_CHECK();
+    const int cand_launch = any_first ? d.CC : d.C * d.gmax;
+    if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.cand_p0, d.cand_p1, d.cand_st, d.cand_count, d.CC, cand_launch, fe->lk, st))) return rc;
+    if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.cand_count, d.CC, cand_launch, fe->lk, st))) return rc;
+    size_t fin_lds = sizeof(unsigned long long) * d.NSORT + sizeof(int) * (2 * d.C * d.gmin + 2 * d.C + 3 * (d.C + 1) + 4);
+    hipLaunchKernelGGL(finalize_kernel, dim3(S), dim3(256), fin_lds, st, d, par);
+    AV_LAUNCH_CHECK();
+    fe->parity = par ^ 1;
+    return AV_OK;
+}
+
+}  // namespace
+
+AV_EXPORT int av_frontend_create(const av_frontend_config* cfg, int n_streams, int device, av_frontend** out)
+{
+    if (!cfg || !out || n_streams <= 0) { av_set_error("av_frontend_create: bad arguments"); return AV_E_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { av_set_error("av_frontend_create: no HIP device visible"); return AV_E_NODEVICE; }
+    if (device < 0 || device >= ndev) { av_set_error("av_frontend_create: device %d out of range (%d visible)", device, ndev); return AV_E_INVALID; }
+    const int C = cfg->grid_row * cfg->grid_col;
+    if (cfg->grid_row <= 0 || cfg->grid_col <= 0 || C > 256 || cfg->grid_min_feature_num <= 0 || cfg->grid_max_feature_num <= 0 ||
+        cfg->lk_levels < 1 || cfg->lk_levels > AV_MAX_LEVELS || cfg->max_corners <= 0) {
+        av_set_error("av_frontend_create: unsupported configuration (grid %dx%d, levels %d)", cfg->grid_row, cfg->grid_col, cfg->lk_levels);
+        return AV_E_INVALID;
+    }
+    AV_HIP(hipSetDevice(device));
+    av_frontend* fe = new (std::nothrow) av_frontend(n_streams);
+    if (!fe) { av_set_error("out of host memory"); return AV_E_INVALID; }
+    fe->cfg = *cfg; fe->device = device;
+    int rc = av_pyramid_layout(cfg->width, cfg->height, cfg->lk_levels, &fe->lay);
+    if (rc) { delete fe; return rc; }
+    fe->geom = av_make_geom(fe->lay);
+    fe->lk.win = cfg->lk_win;
+    fe->lk.max_iter = cfg->lk_max_iter < 0 ? 0 : (cfg->lk_max_iter > 100 ? 100 : cfg->lk_max_iter);
+    double e = cfg->lk_eps < 0 ? 0. : (cfg->lk_eps > 10. ? 10. : cfg->lk_eps);
+    fe->lk.eps2 = e * e;
+    fe->lk.min_eig = cfg->lk_min_eig;
+    if (fe->lk.win != 15) { av_set_error("av_frontend_create: only lk_win = 15 is built"); delete fe; return AV_E_INVALID; }
+
+    FeDev& d = fe->d;
+    memset(&d, 0, sizeof(d));
+    const int S = n_streams, w = cfg->width, h = cfg->height;
+    d.S = S; d.w = w; d.h = h; d.C = C; d.grid_row = cfg->grid_row; d.grid_col = cfg->grid_col;
+    d.gh = (h + cfg->grid_row - 1) / cfg->grid_row;          // int(np.ceil(h / grid_row)), feature_tracker.py:70-71
+    d.gw = (w + cfg->grid_col - 1) / cfg->grid_col;
+    d.gmin = cfg->grid_min_feature_num; d.gmax = cfg->grid_max_feature_num;
+    d.MAXF = C * d.gmax; d.NT = d.MAXF;
+    d.CC = cfg->max_corners > C * d.gmax ? cfg->max_corners : C * d.gmax;
+    d.cell_cap = (d.gh * d.gw) / 4 + 64;
+    if (d.cell_cap > d.CC) d.cell_cap = d.CC;
+    int ns = 2; while (ns < C * (d.gmax + d.gmin)) ns <<= 1;
+    d.NSORT = ns;
+    if (ns > 4096) { av_set_error("av_frontend_create: grid_num*(grid_max+grid_min) = %d exceeds 4096", C * (d.gmax + d.gmin)); delete fe; return AV_E_INVALID; }
+    d.cam0 = CamModel{cfg->cam0_intrinsics[0], cfg->cam0_intrinsics[1], cfg->cam0_intrinsics[2], cfg->cam0_intrinsics[3],
+                      cfg->cam0_distortion[0], cfg->cam0_distortion[1], cfg->cam0_distortion[2], cfg->cam0_distortion[3]};
+    d.cam1 = CamModel{cfg->cam1_intrinsics[0], cfg->cam1_intrinsics[1], cfg->cam1_intrinsics[2], cfg->cam1_intrinsics[3],
+                      cfg->cam1_distortion[0], cfg->cam1_distortion[1], cfg->cam1_distortion[2], cfg->cam1_distortion[3]};
+    for (int i = 0; i < 9; ++i) { d.R0to1[i] = cfg->R0to1[i]; d.E[i] = cfg->E[i]; d.I3[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    d.epi_thr = cfg->stereo_threshold * cfg->norm_unit;
+
+#define A(ptr, n) if ((rc = dev_alloc(fe, &(ptr), (size_t)(n)))) { av_frontend_destroy(fe); return rc; }
+    for (int b = 0; b < 2; ++b) {
+        A(d.feat_id[b], S * d.MAXF) A(d.feat_life[b], S * d.MAXF) A(d.feat_p0[b], 2 * S * d.MAXF) A(d.feat_p1[b], 2 * S * d.MAXF)
+        A(d.feat_cell[b], S * d.MAXF) A(d.n_feat[b], S)
+    }
+    A(d.next_id, S)
+    if ((rc = dev_alloc(fe, &d.first_frame, (size_t)S, 1))) { av_frontend_destroy(fe); return rc; }   // bytes 0x01 -> non-zero ints
+    A(fe->dH, 9 * S)
+    d.Hmat = fe->dH;
+    A(d.trk_prev, 2 * S * d.NT) A(d.trk_next, 2 * S * d.NT) A(d.trk_status, S * d.NT)
+    A(d.sv_src, S * d.NT) A(d.sv_p0, 2 * S * d.NT) A(d.sv_init, 2 * S * d.NT) A(d.sv_p1, 2 * S * d.NT) A(d.sv_st, S * d.NT)
+    A(d.sv_back, 2 * S * d.NT) A(d.sv_st2, S * d.NT)
+    A(d.cur_id, S * d.NT) A(d.cur_life, S * d.NT) A(d.cur_p0, 2 * S * d.NT) A(d.cur_p1, 2 * S * d.NT) A(d.cur_cell, S * d.NT)
+    A(d.cell_kp, (size_t)S * C * d.cell_cap)
+    if ((rc = dev_alloc(fe, &d.mask, (size_t)S * w * h, 1))) { av_frontend_destroy(fe); return rc; }
+    A(d.cand_key, (size_t)S * d.CC) A(d.cand_p0, 2 * (size_t)S * d.CC) A(d.cand_init, 2 * (size_t)S * d.CC) A(d.cand_p1, 2 * (size_t)S * d.CC)
+    A(d.cand_st, (size_t)S * d.CC) A(d.cand_back, 2 * (size_t)S * d.CC) A(d.cand_st2, (size_t)S * d.CC) A(d.cand_inl, (size_t)S * d.CC)
+    A(d.cand_off, S * (C + 1))
+    A(d.out_ids, S * d.MAXF) A(d.out_uv, 4 * S * d.MAXF) A(d.out_n, S)
+    // per-step zeroed counters in one region: trk_count, sv_count, cur_count, cand_count, cell_count, counters
+    {
+        size_t n_int = (size_t)S * 4 + (size_t)S * C + (size_t)S * NCNT;
+        int* z = nullptr;
+        A(z, n_int)
+        fe->zero_region = z; fe->zero_bytes = n_int * sizeof(int);
+        d.trk_count = z; d.sv_count = z + S; d.cur_count = z + 2 * S; d.cand_count = z + 3 * S;
+        d.cell_count = z + 4 * S; d.counters = z + 4 * S + (size_t)S * C;
+    }
+    A(fe->pyr, (size_t)S * 3 * fe->lay.bytes)
+#undef A
+    for (int i = 0; i < 8; ++i) {
+        if (hipHostMalloc((void**)&fe->hH[i], sizeof(double) * 9 * S, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&fe->hH_ev[i], hipEventDisableTiming) != hipSuccess) {
+            av_set_error("av_frontend_create: pinned staging allocation failed");
+            av_frontend_destroy(fe);
+            return AV_E_HIP;
+        }
+    }
+    fe->h_ids.resize((size_t)S * d.MAXF); fe->h_uv.resize((size_t)4 * S * d.MAXF); fe->h_n.resize(S);
+    *out = fe;
+    return AV_OK;
+}
+
+AV_EXPORT void av_frontend_destroy(av_frontend* fe)
+{
+    if (!fe) return;
+    (void)hipSetDevice(fe->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : fe->allocs) (void)hipFree(p);
+    if (fe->stage_img) (void)hipFree(fe->stage_img);
+    for (int i = 0; i < 8; ++i) {
+        if (fe->hH[i]) { (void)hipHostFree(fe->hH[i]); (void)hipEventDestroy(fe->hH_ev[i]); }
+    }
+    delete fe;
+}
+
+AV_EXPORT int av_frontend_push_imu(av_frontend* fe, int stream, double timestamp, const double gyro[3])
+{
+    if (!fe || stream < 0 || stream >= fe->d.S || !gyro) { av_set_error("av_frontend_push_imu: bad arguments"); return AV_E_INVALID; }
+    StreamHost& sh = fe->streams[stream];
+    std::lock_guard<std::mutex> g(sh.mu);
+    sh.imu.push_back(ImuSample{timestamp, {gyro[0], gyro[1], gyro[2]}});
+    return AV_OK;
+}
+
+AV_EXPORT int av_frontend_step(av_frontend* fe, const uint8_t* img0_dev, const uint8_t* img1_dev, int64_t img_stride,
+                               const double* timestamps, void* stream)
+{
+    if (!fe || !img0_dev || !img1_dev || !timestamps || img_stride < (int64_t)fe->d.w * fe->d.h) {
+        av_set_error("av_frontend_step: bad arguments");
+        return AV_E_INVALID;
+    }
+    return step_impl(fe, img0_dev, img1_dev, img_stride, timestamps, (hipStream_t)stream);
+}
+
+AV_EXPORT int av_frontend_step_host(av_frontend* fe, const uint8_t* img0_host, const uint8_t* img1_host, int64_t img_stride,
+                                    const double* timestamps, void* stream)
+{
+    if (!fe || !img0_host || !img1_host || !timestamps || img_stride < (int64_t)fe->d.w * fe->d.h) {
+        av_set_error("av_frontend_step_host: bad arguments");
+        return AV_E_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t img_bytes = (size_t)fe->d.w * fe->d.h;
+    AV_HIP(hipSetDevice(fe->device));
+    if (!fe->stage_img) AV_HIP(hipMalloc((void**)&fe->stage_img, 2 * img_bytes * fe->d.S));
+    uint8_t* s0 = fe->stage_img; uint8_t* s1 = fe->stage_img + img_bytes * fe->d.S;
+    AV_HIP(hipMemcpy2DAsync(s0, img_bytes, img0_host, (size_t)img_stride, img_bytes, fe->d.S, hipMemcpyHostToDevice, st));
+    AV_HIP(hipMemcpy2DAsync(s1, img_bytes, img1_host, (size_t)img_stride, img_bytes, fe->d.S, hipMemcpyHostToDevice, st));
+    return step_impl(fe, s0, s1, (int64_t)img_bytes, timestamps, st);
+}
+
+AV_EXPORT int av_frontend_max_features(const av_frontend* fe) { return fe ? fe->d.MAXF : AV_E_INVALID; }
+
+AV_EXPORT int av_frontend_read_features(av_frontend* fe, int64_t* ids_out, double* uv_out, int32_t* n_out, int cap, void* stream)
+{
+    if (!fe || !ids_out || !uv_out || !n_out || cap < fe->d.MAXF) { av_set_error("av_frontend_read_features: bad arguments"); return AV_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    const FeDev& d = fe->d;
+    AV_HIP(hipSetDevice(fe->device));
+    AV_HIP(hipMemcpyAsync(fe->h_n.data(), d.out_n, sizeof(int) * d.S, hipMemcpyDeviceToHost, st));
+    AV_HIP(hipMemcpyAsync(fe->h_ids.data(), d.out_ids, sizeof(long long) * d.S * d.MAXF, hipMemcpyDeviceToHost, st));
+    AV_HIP(hipMemcpyAsync(fe->h_uv.data(), d.out_uv, sizeof(double) * 4 * d.S * d.MAXF, hipMemcpyDeviceToHost, st));
+    std::vector<int> cnt((size_t)d.S * NCNT);
+    AV_HIP(hipMemcpyAsync(cnt.data(), d.counters, sizeof(int) * d.S * NCNT, hipMemcpyDeviceToHost, st));
+    AV_HIP(hipStreamSynchronize(st));
+    int ovf = 0;
+    for (int s = 0; s < d.S; ++s) {
+        int n = fe->h_n[s];
+        n_out[s] = n;
+        for (int k = 0; k < n; ++k) {
+            ids_out[(size_t)s * cap + k] = fe->h_ids[(size_t)s * d.MAXF + k];
+            for (int j = 0; j < 4; ++j) uv_out[((size_t)s * cap + k) * 4 + j] = fe->h_uv[((size_t)s * d.MAXF + k) * 4 + j];
+        }
+        ovf |= cnt[(size_t)s * NCNT + CNT_OVF];
+    }
+    if (ovf) { av_set_error("front-end device buffer overflow (flags 0x%x): raise max_corners", ovf); return AV_E_CAPACITY; }
+    return AV_OK;
+}
+
+AV_EXPORT int av_frontend_read_grid(av_frontend* fe, int stream_idx, int64_t* ids, int32_t* lifetime, int32_t* cell,
+                                    float* pts, int cap, int32_t* n_out, int64_t* next_feature_id, void* stream)
+{
+    if (!fe || stream_idx < 0 || stream_idx >= fe->d.S || !ids || !lifetime || !cell || !pts || !n_out || cap < fe->d.MAXF) {
+        av_set_error("av_frontend_read_grid: bad arguments");
+        return AV_E_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const FeDev& d = fe->d;
+    const int b = fe->parity;        // after a step, parity indexes the grid just published
+    const size_t o = (size_t)stream_idx * d.MAXF;
+    AV_HIP(hipSetDevice(fe->device));
+    AV_HIP(hipStreamSynchronize(st));
+    int n = 0; long long nid = 0;
+    AV_HIP(hipMemcpy(&n, d.n_feat[b] + stream_idx, sizeof(int), hipMemcpyDeviceToHost));
+    AV_HIP(hipMemcpy(&nid, d.next_id + stream_idx, sizeof(long long), hipMemcpyDeviceToHost));
+    std::vector<float> p0(2 * (size_t)d.MAXF), p1(2 * (size_t)d.MAXF);
+    std::vector<long long> idv(d.MAXF);
+    AV_HIP(hipMemcpy(idv.data(), d.feat_id[b] + o, sizeof(long long) * d.MAXF, hipMemcpyDeviceToHost));
+    AV_HIP(hipMemcpy(lifetime, d.feat_life[b] + o, sizeof(int) * d.MAXF, hipMemcpyDeviceToHost));
+    AV_HIP(hipMemcpy(cell, d.feat_cell[b] + o, sizeof(int) * d.MAXF, hipMemcpyDeviceToHost));
+    AV_HIP(hipMemcpy(p0.data(), d.feat_p0[b] + 2 * o, sizeof(float) * 2 * d.MAXF, hipMemcpyDeviceToHost));
+    AV_HIP(hipMemcpy(p1.data(), d.feat_p1[b] + 2 * o, sizeof(float) * 2 * d.MAXF, hipMemcpyDeviceToHost));
+    for (int k = 0; k < n; ++k) {
+        ids[k] = idv[k];
+        pts[4 * k] = p0[2 * k]; pts[4 * k + 1] = p0[2 * k + 1]; pts[4 * k + 2] = p1[2 * k]; pts[4 * k + 3] = p1[2 * k + 1];
+    }
+    *n_out = n;
+    if (next_feature_id) *next_feature_id = nid;
+    return AV_OK;
+}
+
+AV_EXPORT int av_frontend_read_counters(av_frontend* fe, int stream_idx, int32_t out[8], void* stream)
+{
+    if (!fe || stream_idx < 0 || stream_idx >= fe->d.S || !out) { av_set_error("av_frontend_read_counters: bad arguments"); return AV_E_INVALID; }
+    AV_HIP(hipSetDevice(fe->device));
+    AV_HIP(hipStreamSynchronize((hipStream_t)stream));
+    AV_HIP(hipMemcpy(out, fe->d.counters + (size_t)stream_idx * NCNT, sizeof(int) * NCNT, hipMemcpyDeviceToHost));
+    return AV_OK;
+}

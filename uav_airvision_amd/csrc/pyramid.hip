@@ -1,0 +1,173 @@
+// pyramid.hip -- padded u8 Gaussian pyramids for LK (gfx950).
+//
+// Replaces the pyrDown chain that cv2.calcOpticalFlowPyrLK rebuilds inside every call
+// (reference: src/image_processing/pyramid_builder.py:22-48 is a pass-through, SURVEY.md F2;
+// call sites feature_tracker.py:102, stereo_matcher.py:64,70).  Built ONCE per image here and
+// kept resident; the prev-cam0 pyramid is reused by the next frame.
+//
+// Layout: every level is stored with a 16-pixel BORDER_REFLECT_101 frame (AV_PYR_BORDER), so the
+// LK kernel never clamps or reflects a coordinate.  Both kernels are written as pure gathers over
+// the PADDED destination: a destination pixel in the frame recomputes the value of the interior
+// pixel it mirrors, so there is no scatter and no separate border pass.
+//
+// Roofline: HBM-bound streaming (level 0: w*h read + padded write; levels 1..3: 1/4, 1/16, 1/64
+// of that).  Integer arithmetic only: separable [1 4 6 4 1], (sum + 128) >> 8.
+#include "av_common.h"
+
+namespace {
+
+struct PyrArgs {
+    const uint8_t* img0;
+    const uint8_t* img1;
+    int64_t img_stride;
+    int imgs_per_stream;
+    uint8_t* pyr_base;
+    int64_t stream_stride, slot_stride;
+    int slot0, slot1;
+    PyrGeom g;
+};
+
+__device__ __forceinline__ uint8_t* pyr_of(const PyrArgs& a, int img)
+{
+    int s = img / a.imgs_per_stream, cam = img - s * a.imgs_per_stream;
+    return a.pyr_base + s * a.stream_stride + (cam == 0 ? a.slot0 : a.slot1) * a.slot_stride;
+}
+
+// level 0: copy the tightly packed input image into the padded level, frame included.
+__global__ __launch_bounds__(256) void pad_level0_kernel(PyrArgs a)
+{
+    const int w = a.g.w[0], h = a.g.h[0], pitch = a.g.pitch[0];
+    const int quads_per_row = pitch >> 2;
+    const int ph = h + 2 * AV_PYR_BORDER;
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= quads_per_row * ph) return;
+    int yp = q / quads_per_row, xq = q - yp * quads_per_row;
+    int img = blockIdx.y;
+    int s = img / a.imgs_per_stream, cam = img - s * a.imgs_per_stream;
+    const uint8_t* src = (cam == 0 ? a.img0 : a.img1) + s * a.img_stride;
+    uint8_t* dst = pyr_of(a, img) + a.g.off[0];
+    int y = av_reflect101(yp - AV_PYR_BORDER, h);
+    const uint8_t* row = src + (size_t)y * w;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int xp = xq * 4 + i;
+        int x = av_reflect101(xp - AV_PYR_BORDER, w);
+        x = min(max(x, 0), w - 1);          // slack columns beyond w+32 (pitch rounding): any valid pixel
+        out |= (uint32_t)row[x] << (8 * i);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)yp * pitch + xq * 4) = out;
+}
+
+// level l (>= 1) from padded level l-1.
+__global__ __launch_bounds__(256) void pyr_down_kernel(PyrArgs a, int level)
+{
+    const int w = a.g.w[level], h = a.g.h[level], pitch = a.g.pitch[level];
+    const int spitch = a.g.pitch[level - 1];
+    const int quads_per_row = pitch >> 2;
+    const int ph = h + 2 * AV_PYR_BORDER;
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= quads_per_row * ph) return;
+    int yp = q / quads_per_row, xq = q - yp * quads_per_row;
+    uint8_t* base = pyr_of(a, blockIdx.y);
+    const uint8_t* src = base + a.g.off[level - 1];
+    uint8_t* dst = base + a.g.off[level];
+    int y = av_reflect101(yp - AV_PYR_BORDER, h);
+    // padded source rows 2y-2 .. 2y+2
+    const uint8_t* r0 = src + (size_t)(2 * y - 2 + AV_PYR_BORDER) * spitch + AV_PYR_BORDER;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int xp = xq * 4 + i;
+        int x = av_reflect101(xp - AV_PYR_BORDER, w);
+        x = min(max(x, 0), w - 1);
+        const uint8_t* p = r0 + 2 * x;
+        int hsum[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const uint8_t* r = p + (size_t)k * spitch;
+            hsum[k] = (int)r[-2] + (int)r[2] + 4 * ((int)r[-1] + (int)r[1]) + 6 * (int)r[0];
+        }
+        int v = hsum[0] + hsum[4] + 4 * (hsum[1] + hsum[3]) + 6 * hsum[2];
+        out |= (uint32_t)((v + 128) >> 8) << (8 * i);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)yp * pitch + xq * 4) = out;
+}
+
+}  // namespace
+
+PyrGeom av_make_geom(const av_pyr_layout& l)
+{
+    PyrGeom g;
+    memset(&g, 0, sizeof(g));
+    g.levels = l.levels;
+    for (int i = 0; i < l.levels; ++i) {
+        g.w[i] = l.w[i]; g.h[i] = l.h[i]; g.pitch[i] = l.pitch[i]; g.off[i] = (int)l.offset[i];
+    }
+    return g;
+}
+
+int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stride, int n_streams, int imgs_per_stream,
+                      const PyrGeom& g, uint8_t* pyr_base, int64_t stream_stride, int64_t slot_stride, int slot0, int slot1,
+                      hipStream_t st)
+{
+    if (n_streams <= 0) return AV_OK;
+    PyrArgs a;
+    a.img0 = img0; a.img1 = img1; a.img_stride = img_stride; a.imgs_per_stream = imgs_per_stream;
+    a.pyr_base = pyr_base; a.stream_stride = stream_stride; a.slot_stride = slot_stride;
+    a.slot0 = slot0; a.slot1 = slot1; a.g = g;
+    const int n_img = n_streams * imgs_per_stream;
+    {
+        int quads = (g.pitch[0] >> 2) * (g.h[0] + 2 * AV_PYR_BORDER);
+        dim3 grid((quads + 255) / 256, n_img);
+        hipLaunchKernelGGL(pad_level0_kernel, grid, dim3(256), 0, st, a);
+        AV_LAUNCH_CHECK();
+    }
+    for (int l = 1; l < g.levels; ++l) {
+        int quads = (g.pitch[l] >> 2) * (g.h[l] + 2 * AV_PYR_BORDER);
+        dim3 grid((quads + 255) / 256, n_img);
+        hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, st, a, l);
+        AV_LAUNCH_CHECK();
+    }
+    return AV_OK;
+}
+
+AV_EXPORT int av_pyramid_layout(int w, int h, int levels, av_pyr_layout* out)
+{
+    if (!out || levels < 1 || levels > AV_MAX_LEVELS || w <= 0 || h <= 0) {
+        av_set_error("av_pyramid_layout: bad arguments (w=%d h=%d levels=%d)", w, h, levels);
+        return AV_E_INVALID;
+    }
+    memset(out, 0, sizeof(*out));
+    out->levels = levels;
+    int64_t off = 0;
+    int lw = w, lh = h;
+    for (int l = 0; l < levels; ++l) {
+        if (lw <= AV_PYR_BORDER || lh <= AV_PYR_BORDER) {
+            av_set_error("av_pyramid_layout: level %d is %dx%d, too small for a %d-pixel reflect-101 frame", l, lw, lh, AV_PYR_BORDER);
+            return AV_E_INVALID;
+        }
+        out->w[l] = lw; out->h[l] = lh;
+        out->pitch[l] = ((lw + 2 * AV_PYR_BORDER) + 15) & ~15;
+        out->offset[l] = off;
+        off += (int64_t)out->pitch[l] * (lh + 2 * AV_PYR_BORDER);
+        lw = (lw + 1) / 2; lh = (lh + 1) / 2;
+    }
+    out->bytes = (off + 255) & ~(int64_t)255;
+    if (out->bytes > 0x7fffffff) { av_set_error("av_pyramid_layout: image too large"); return AV_E_INVALID; }
+    return AV_OK;
+}
+
+AV_EXPORT int av_pyramid_build(const uint8_t* img_dev, int64_t img_stride, int n_img, int w, int h, int levels,
+                               uint8_t* pyr_dev, int64_t pyr_stride, void* stream)
+{
+    av_pyr_layout lay;
+    int rc = av_pyramid_layout(w, h, levels, &lay);
+    if (rc) return rc;
+    if (!img_dev || !pyr_dev || n_img < 0 || pyr_stride < lay.bytes || img_stride < (int64_t)w * h) {
+        av_set_error("av_pyramid_build: bad arguments");
+        return AV_E_INVALID;
+    }
+    return av_launch_pyramid(img_dev, nullptr, img_stride, n_img, 1, av_make_geom(lay), pyr_dev, pyr_stride, 0, 0, 0,
+                             (hipStream_t)stream);
+}
