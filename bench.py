@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo frames/s of the MI355X image front-end on synthetic 752x480 streams.
+
+Workload = BASELINE.json configs[1]: "Synthetic 752x480 stereo stream, 300 tracked features,
+LK+stereo kernels on 1 MI355X" -- the reference front-end (ImageProcessingPipeline.stereo_callback:
+temporal LK, stereo LK fwd/bwd + gates, FAST + grid add/prune, publish) with grid 4x5 x 15 = 300
+features per frame, run for S independent streams per GPU (frames of one stream are sequential,
+streams are the parallel axis).  One "step" = one stereo frame of every stream.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  Inputs are resident in HBM before
+the timed region; IMU samples are pushed from the host inside it (they are part of the path).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W_IMG, H_IMG = 752, 480
+LK_BYTES_PER_POINT_PASS = 4 * 2 * 289 + 25          # L=4 levels x (I + J window of 17x17) + point I/O
+HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def frame_bytes(n_t, n_trk, n_cand):
+    """Algorithmic bytes of one stereo frame: 2 images + 2x3 pyramid levels + LK point passes."""
+    p = n_t + 2 * n_trk + 2 * n_cand
+    return 2 * W_IMG * H_IMG + 2 * 118440 + p * LK_BYTES_PER_POINT_PASS, p
+
+
+def make_config():
+    from uav_airvision_amd.config import ConfigEuRoC
+    return ConfigEuRoC(grid_row=4, grid_col=5, grid_min_feature_num=3, grid_max_feature_num=15)
+
+
+def cpu_baseline(cfg, budget_s=12.0, max_frames=40):
+    """The CPU oracle (oracle/, scalar C ops + Python glue = a port of the reference's CPU path) on
+    ONE stream of the same workload, single thread, bounded sample."""
+    from oracle.frontend import OracleFrontend
+    from uav_airvision_amd.synth import SyntheticStream
+    st = SyntheticStream(cfg, seed=0, n_frames=max_frames)
+    frames = []
+    fe = OracleFrontend(cfg, cache_pyramids=True)
+    it = iter(st.imu)
+    pend = next(it, None)
+    n = 0
+    spent = 0.0
+    warm = 8                                   # let the grid fill up to ~300 features first (not timed)
+    for k in range(max_frames):
+        m = st.frame(k)
+        while pend is not None and pend.timestamp <= m.timestamp:
+            fe.imu_callback(pend)
+            pend = next(it, None)
+        t0 = time.perf_counter()
+        msg = fe.stereo_callback(m)
+        dt = time.perf_counter() - t0
+        if k >= warm:
+            spent += dt
+            n += 1
+            frames.append(len(msg.features))
+            if spent >= budget_s:
+                break
+    return dict(value=n / spent, unit='stereo frames/s', cores=1, kind='port',
+                sample='%d frames of 1 synthetic stream after %d warm-up frames, %.1f s, mean %d features/frame'
+                       % (n, warm, spent, int(np.mean(frames))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--streams', type=int, default=64, help='independent stereo streams per GPU')
+    ap.add_argument('--unique', type=int, default=4, help='distinct rendered streams (replicated with per-stream noise)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from uav_airvision_amd.frontend import FrontendEngine
+    from uav_airvision_amd.synth import SyntheticStream
+
+    cfg = make_config()
+    S, K, Wm = args.streams, args.steps, args.warmup
+    F = Wm + K
+    # config/seed broadcast from rank 0 over RCCL (config broadcast, no data-path collective)
+    seed_t = torch.tensor([1234 if rank == 0 else 0], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.broadcast(seed_t, 0)
+    base_seed = int(seed_t.item())
+
+    # ---- synthetic data: U rendered streams, replicated to S streams with per-stream pixel noise ----
+    U = max(1, min(args.unique, S))
+    t_gen = time.time()
+    streams = [SyntheticStream(cfg, seed=base_seed + 97 * rank + u, n_frames=F) for u in range(U)]
+    base0 = np.empty((U, F, H_IMG, W_IMG), np.uint8)
+    base1 = np.empty((U, F, H_IMG, W_IMG), np.uint8)
+    for u, st in enumerate(streams):
+        for k in range(F):
+            m = st.frame(k)
+            base0[u, k] = m.cam0_image
+            base1[u, k] = m.cam1_image
+    g = torch.Generator(device=dev)
+    g.manual_seed(base_seed + rank)
+    img0 = torch.empty((F, S, H_IMG, W_IMG), dtype=torch.uint8, device=dev)
+    img1 = torch.empty((F, S, H_IMG, W_IMG), dtype=torch.uint8, device=dev)
+    b0 = torch.from_numpy(base0).to(dev)
+    b1 = torch.from_numpy(base1).to(dev)
+    for s in range(S):
+        u = s % U
+        for dst, src in ((img0, b0), (img1, b1)):
+            noise = torch.randint(-2, 3, (F, H_IMG, W_IMG), generator=g, device=dev, dtype=torch.int16)
+            dst[:, s] = (src[u].to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
+    del b0, b1
+    # IMU samples per step, all streams, as flat arrays for the batched push
+    imu_steps = []
+    its = [iter(st.imu) for st in streams]
+    pend = [next(it, None) for it in its]
+    for k in range(F):
+        idx, ts, gy = [], [], []
+        for u, st in enumerate(streams):
+            tf = st.frame_time(k)
+            batch = []
+            while pend[u] is not None and pend[u].timestamp <= tf:
+                batch.append(pend[u])
+                pend[u] = next(its[u], None)
+            for s in range(u, S, U):
+                for m in batch:
+                    idx.append(s); ts.append(m.timestamp); gy.append(m.angular_velocity)
+        imu_steps.append((np.array(idx, np.int32), np.array(ts, np.float64), np.array(gy, np.float64).reshape(-1, 3)))
+    frame_ts = [[streams[s % U].frame_time(k) for s in range(S)] for k in range(F)]
+    gen_s = time.time() - t_gen
+
+    eng = FrontendEngine(cfg, n_streams=S, device=local_rank)
+
+    def run(k):
+        i, t, gy = imu_steps[k]
+        eng.push_imu_batch(i, t, gy)
+        eng.step(img0[k], img1[k], frame_ts[k])
+
+    for k in range(Wm):
+        run(k)
+    eng.read_features()                              # sync + overflow check of the warm-up
+    eng.enable_timing(16 * K + 16)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(Wm, F):
+        run(k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    timing = eng.read_timing()
+    feats = eng.read_features()                      # raises on any device-side overflow
+    cnts = eng.read_all_counters()
+    n_t = float(np.mean([c['before_tracking'] for c in cnts]))
+    n_trk = float(np.mean([c['after_tracking'] for c in cnts]))
+    n_cand = float(np.mean([c['n_candidates'] for c in cnts]))
+    n_pub = float(np.mean([len(f[0]) for f in feats]))
+    stats = torch.tensor([n_t, n_trk, n_cand, n_pub], dtype=torch.float64, device=dev)
+    if world > 1:                                    # trajectory/counter gather is the only end-of-run exchange
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        stats /= world
+    n_t, n_trk, n_cand, n_pub = [float(v) for v in stats.tolist()]
+
+    fps = world * S * K / elapsed
+    b_frame, p_frame = frame_bytes(n_t, n_trk, n_cand)
+    lk_ms, lk_n = timing['lk']
+    lk_avg_ms = lk_ms / max(lk_n, 1)
+    lk_bytes_per_launch = S * p_frame * LK_BYTES_PER_POINT_PASS / 5.0       # 5 LK launches per step
+    lk_gbs = lk_bytes_per_launch / (lk_avg_ms * 1e-3) / 1e9 if lk_avg_ms > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            'metric': 'stereo frames/sec (LK+stereo front-end) at 752x480',
+            'value': fps, 'unit': 'stereo frames/s', 'n_gpus': world, 'steps': K, 'warmup': Wm,
+            'ms_per_step': 1e3 * elapsed / K, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'u8/int32 windows, f32 normal equations', 'data': 'synthetic',
+            'config': {
+                'workload': 'BASELINE configs[1]: synthetic 752x480 stereo streams, grid 4x5x15 = 300 features/frame, '
+                            'temporal LK + stereo LK fwd/bwd + gates + FAST/grid add/prune/publish on device; MSCKF not in the step',
+                'streams_per_gpu': S, 'unique_rendered_streams': U, 'parallelism': 'stream-sharded x%d' % world,
+                'tracked_features_per_frame': n_t, 'published_features_per_frame': n_pub,
+                'lk_point_passes_per_frame': p_frame, 'algorithmic_bytes_per_frame': b_frame,
+                'frame_hbm_frac': fps / world * b_frame / 1e9 / HBM_PEAK_GBS,
+            },
+            'roofline': {
+                'bound': 'hbm', 'kernel': 'lk_track_kernel<15>',
+                'achieved': lk_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': lk_gbs / HBM_PEAK_GBS,
+                'traffic': None,
+                'avg_launch_ms': lk_avg_ms, 'launches': lk_n, 'algorithmic_bytes_per_launch': lk_bytes_per_launch,
+            },
+            'kernel_ms_per_step': {k: v[0] / K for k, v in timing.items()},
+            'data_gen_s': gen_s,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -138,6 +138,10 @@ void av_frontend_destroy(av_frontend* fe);
  * gyro is used by the front-end.  Thread-safe against av_frontend_step* on other threads. */
 int av_frontend_push_imu(av_frontend* fe, int stream, double timestamp, const double gyro[3]);
 
+/* n IMU samples in one call: sample i goes to stream stream_idx[i]; gyro is [n][3]. */
+int av_frontend_push_imu_batch(av_frontend* fe, const int32_t* stream_idx, const double* timestamps,
+                               const double* gyro, int n);
+
 /* ImageProcessingPipeline.stereo_callback for every stream at once (pipeline.py:46-150).
  * Stream s reads its cam0/cam1 images (tightly packed width*height u8, device memory) at
  * img0_dev + s*img_stride and img1_dev + s*img_stride; timestamps[s] is the frame time.  All
@@ -167,6 +171,14 @@ int av_frontend_read_grid(av_frontend* fe, int stream_idx, int64_t* ids, int32_t
  * adder): [before_tracking, after_tracking, after_matching, n_fast_corners, n_candidates, n_new,
  * n_published, overflow_flags].  Synchronises. */
 int av_frontend_read_counters(av_frontend* fe, int stream_idx, int32_t out[8], void* stream);
+
+/* Measurement hooks (bench.py's roofline leg; no reference counterpart): when enabled, every
+ * launch group of av_frontend_step is bracketed by a HIP event pair ON THE STEP'S STREAM.
+ * max_spans = capacity in event pairs (0 disables).  av_frontend_read_timing synchronises the
+ * device and returns, per kernel class [0 pyramid, 1 LK, 2 FAST, 3 glue], the summed elapsed
+ * milliseconds and the number of launch groups measured since the last read. */
+int av_frontend_enable_timing(av_frontend* fe, int max_spans);
+int av_frontend_read_timing(av_frontend* fe, double ms_out[4], int32_t spans_out[4]);
 
 #ifdef __cplusplus
 }

@@ -60,12 +60,15 @@ SIGNATURES = {
     'av_frontend_create': (C.c_int, [C.POINTER(FrontendConfig), C.c_int, C.c_int, C.POINTER(_P)]),
     'av_frontend_destroy': (None, [_P]),
     'av_frontend_push_imu': (C.c_int, [_P, C.c_int, C.c_double, C.POINTER(C.c_double)]),
+    'av_frontend_push_imu_batch': (C.c_int, [_P, _P, _P, _P, C.c_int]),
     'av_frontend_step': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double), _P]),
     'av_frontend_step_host': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double), _P]),
     'av_frontend_max_features': (C.c_int, [_P]),
     'av_frontend_read_features': (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
     'av_frontend_read_grid': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64), _P]),
     'av_frontend_read_counters': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32 * 8), _P]),
+    'av_frontend_enable_timing': (C.c_int, [_P, C.c_int]),
+    'av_frontend_read_timing': (C.c_int, [_P, C.POINTER(C.c_double * 4), C.POINTER(C.c_int32 * 4)]),
 }
 
 _lib = None

@@ -506,6 +506,9 @@ struct av_frontend {
     std::vector<StreamHost> streams;
     bool any_first = true;
     std::vector<long long> h_ids; std::vector<double> h_uv; std::vector<int> h_n;
+    // optional HIP-event timing per kernel class (bench.py's roofline leg)
+    bool timing = false;
+    std::vector<hipEvent_t> ev; std::vector<int> ev_cls; size_t ev_used = 0;
 
     explicit av_frontend(int S) : streams(S) {}
 };
@@ -561,6 +564,23 @@ int integrate_imu(av_frontend* fe, int s, double t_curr, double* H)
     return AV_OK;
 }
 
+// event pair around a launch group; classes: 0 pyramid, 1 LK, 2 FAST, 3 glue
+struct Span {
+    av_frontend* fe; hipStream_t st; bool on;
+    Span(av_frontend* f, int cls, hipStream_t s) : fe(f), st(s), on(false)
+    {
+        if (fe->timing && fe->ev_used + 2 <= fe->ev.size()) {
+            on = true;
+            fe->ev_cls[fe->ev_used / 2] = cls;
+            (void)hipEventRecord(fe->ev[fe->ev_used], st);
+        }
+    }
+    ~Span()
+    {
+        if (on) { (void)hipEventRecord(fe->ev[fe->ev_used + 1], st); fe->ev_used += 2; }
+    }
+};
+
 int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t img_stride, const double* ts, hipStream_t st)
 {
     FeDev& d = fe->d;
@@ -591,32 +611,45 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
     const int cur0 = par ^ 1;                // curr cam0 pyramid slot (0/1), cam1 pyramid is slot 2
     const int64_t sstride = 3 * fe->lay.bytes, slotb = fe->lay.bytes;
     int rc;
-    if ((rc = av_launch_pyramid(img0, img1, img_stride, S, 2, fe->geom, fe->pyr, sstride, slotb, cur0, 2, st))) return rc;
+    { Span sp(fe, 0, st);
+      if ((rc = av_launch_pyramid(img0, img1, img_stride, S, 2, fe->geom, fe->pyr, sstride, slotb, cur0, 2, st))) return rc; }
 
     const uint8_t* P_prev0 = fe->pyr + par * slotb;
     const uint8_t* P_cur0 = fe->pyr + cur0 * slotb;
     const uint8_t* P_cur1 = fe->pyr + 2 * slotb;
 
-    hipLaunchKernelGGL(track_prepare_kernel, dim3((d.NT + 255) / 256, S), dim3(256), 0, st, d, par);
-    AV_LAUNCH_CHECK();
-    if ((rc = av_launch_lk(P_prev0, P_cur0, sstride, S, fe->geom, d.trk_prev, d.trk_next, d.trk_status, d.trk_count, d.NT, d.NT, fe->lk, st))) return rc;
-    hipLaunchKernelGGL(track_gate_kernel, dim3(S), dim3(256), 0, st, d);
-    AV_LAUNCH_CHECK();
-    if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.sv_p0, d.sv_p1, d.sv_st, d.sv_count, d.NT, d.NT, fe->lk, st))) return rc;
-    if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.sv_p1, d.sv_back, d.sv_st2, d.sv_count, d.NT, d.NT, fe->lk, st))) return rc;
-    hipLaunchKernelGGL(rebin_kernel, dim3(S), dim3(256), 0, st, d, par);
-    AV_LAUNCH_CHECK();
+    { Span sp(fe, 3, st);
+      hipLaunchKernelGGL(track_prepare_kernel, dim3((d.NT + 255) / 256, S), dim3(256), 0, st, d, par);
+      AV_LAUNCH_CHECK(); }
+    { Span sp(fe, 1, st);
+      if ((rc = av_launch_lk(P_prev0, P_cur0, sstride, S, fe->geom, d.trk_prev, d.trk_next, d.trk_status, d.trk_count, d.NT, d.NT, fe->lk, st))) return rc; }
+    { Span sp(fe, 3, st);
+      hipLaunchKernelGGL(track_gate_kernel, dim3(S), dim3(256), 0, st, d);
+      AV_LAUNCH_CHECK(); }
+    { Span sp(fe, 1, st);
+      if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.sv_p0, d.sv_p1, d.sv_st, d.sv_count, d.NT, d.NT, fe->lk, st))) return rc; }
+    { Span sp(fe, 1, st);
+      if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.sv_p1, d.sv_back, d.sv_st2, d.sv_count, d.NT, d.NT, fe->lk, st))) return rc; }
+    { Span sp(fe, 3, st);
+      hipLaunchKernelGGL(rebin_kernel, dim3(S), dim3(256), 0, st, d, par);
+      AV_LAUNCH_CHECK(); }
+    Span* fast_span = new Span(fe, 2, st);
     if ((rc = av_launch_fast(img0, img_stride, d.w, d.mask, (int64_t)d.w * d.h, S, d.w, d.h, fe->cfg.fast_threshold,
                              nullptr, nullptr, 0, d.cell_kp, d.cell_count, d.cell_cap, d.gh, d.gw, d.grid_col, d.C,
-                             d.counters + CNT_FAST, d.counters + CNT_OVF, NCNT, st))) return rc;
-    hipLaunchKernelGGL(select_kernel, dim3(S), dim3(256), sizeof(int) * (2 * d.C + 1), st, d);
-    AV_LAUNCH_CHECK();
+                             d.counters + CNT_FAST, d.counters + CNT_OVF, NCNT, st))) { delete fast_span; return rc; }
+    delete fast_span;
+    { Span sp(fe, 3, st);
+      hipLaunchKernelGGL(select_kernel, dim3(S), dim3(256), sizeof(int) * (2 * d.C + 1), st, d);
+      AV_LAUNCH_CHECK(); }
     const int cand_launch = any_first ? d.CC : d.C * d.gmax;
-    if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.cand_p0, d.cand_p1, d.cand_st, d.cand_count, d.CC, cand_launch, fe->lk, st))) return rc;
-    if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.cand_count, d.CC, cand_launch, fe->lk, st))) return rc;
+    { Span sp(fe, 1, st);
+      if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.cand_p0, d.cand_p1, d.cand_st, d.cand_count, d.CC, cand_launch, fe->lk, st))) return rc; }
+    { Span sp(fe, 1, st);
+      if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.cand_count, d.CC, cand_launch, fe->lk, st))) return rc; }
     size_t fin_lds = sizeof(unsigned long long) * d.NSORT + sizeof(int) * (2 * d.C * d.gmin + 2 * d.C + 3 * (d.C + 1) + 4);
-    hipLaunchKernelGGL(finalize_kernel, dim3(S), dim3(256), fin_lds, st, d, par);
-    AV_LAUNCH_CHECK();
+    { Span sp(fe, 3, st);
+      hipLaunchKernelGGL(finalize_kernel, dim3(S), dim3(256), fin_lds, st, d, par);
+      AV_LAUNCH_CHECK(); }
     fe->parity = par ^ 1;
     return AV_OK;
 }
@@ -719,6 +752,7 @@ AV_EXPORT void av_frontend_destroy(av_frontend* fe)
     (void)hipSetDevice(fe->device);
     (void)hipDeviceSynchronize();
     for (void* p : fe->allocs) (void)hipFree(p);
+    for (hipEvent_t e : fe->ev) (void)hipEventDestroy(e);
     if (fe->stage_img) (void)hipFree(fe->stage_img);
     for (int i = 0; i < 8; ++i) {
         if (fe->hH[i]) { (void)hipHostFree(fe->hH[i]); (void)hipEventDestroy(fe->hH_ev[i]); }
@@ -732,6 +766,17 @@ AV_EXPORT int av_frontend_push_imu(av_frontend* fe, int stream, double timestamp
     StreamHost& sh = fe->streams[stream];
     std::lock_guard<std::mutex> g(sh.mu);
     sh.imu.push_back(ImuSample{timestamp, {gyro[0], gyro[1], gyro[2]}});
+    return AV_OK;
+}
+
+AV_EXPORT int av_frontend_push_imu_batch(av_frontend* fe, const int32_t* stream_idx, const double* timestamps,
+                                         const double* gyro, int n)
+{
+    if (!fe || !stream_idx || !timestamps || !gyro || n < 0) { av_set_error("av_frontend_push_imu_batch: bad arguments"); return AV_E_INVALID; }
+    for (int i = 0; i < n; ++i) {
+        int rc = av_frontend_push_imu(fe, stream_idx[i], timestamps[i], gyro + 3 * (size_t)i);
+        if (rc) return rc;
+    }
     return AV_OK;
 }
 
@@ -828,5 +873,38 @@ AV_EXPORT int av_frontend_read_counters(av_frontend* fe, int stream_idx, int32_t
     AV_HIP(hipSetDevice(fe->device));
     AV_HIP(hipStreamSynchronize((hipStream_t)stream));
     AV_HIP(hipMemcpy(out, fe->d.counters + (size_t)stream_idx * NCNT, sizeof(int) * NCNT, hipMemcpyDeviceToHost));
+    return AV_OK;
+}
+
+AV_EXPORT int av_frontend_enable_timing(av_frontend* fe, int max_spans)
+{
+    if (!fe || max_spans < 0) { av_set_error("av_frontend_enable_timing: bad arguments"); return AV_E_INVALID; }
+    AV_HIP(hipSetDevice(fe->device));
+    AV_HIP(hipDeviceSynchronize());
+    for (hipEvent_t e : fe->ev) (void)hipEventDestroy(e);
+    fe->ev.clear(); fe->ev_cls.clear(); fe->ev_used = 0;
+    fe->timing = max_spans > 0;
+    for (int i = 0; i < 2 * max_spans; ++i) {
+        hipEvent_t e;
+        AV_HIP(hipEventCreate(&e));
+        fe->ev.push_back(e);
+    }
+    fe->ev_cls.assign((size_t)max_spans, 0);
+    return AV_OK;
+}
+
+AV_EXPORT int av_frontend_read_timing(av_frontend* fe, double ms_out[4], int32_t spans_out[4])
+{
+    if (!fe || !ms_out || !spans_out) { av_set_error("av_frontend_read_timing: bad arguments"); return AV_E_INVALID; }
+    AV_HIP(hipSetDevice(fe->device));
+    AV_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < 4; ++i) { ms_out[i] = 0.0; spans_out[i] = 0; }
+    for (size_t k = 0; k + 1 < fe->ev_used; k += 2) {
+        float ms = 0.f;
+        AV_HIP(hipEventElapsedTime(&ms, fe->ev[k], fe->ev[k + 1]));
+        int c = fe->ev_cls[k / 2];
+        ms_out[c] += (double)ms; spans_out[c] += 1;
+    }
+    fe->ev_used = 0;
     return AV_OK;
 }

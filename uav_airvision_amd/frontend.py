@@ -96,6 +96,15 @@ class FrontendEngine(object):
         g = (C.c_double * 3)(float(gyro[0]), float(gyro[1]), float(gyro[2]))
         N.check(N.lib().av_frontend_push_imu(self._h, int(stream), float(timestamp), g))
 
+    def push_imu_batch(self, stream_idx, timestamps, gyro):
+        """stream_idx int32[n], timestamps float64[n], gyro float64[n,3] in one C call."""
+        si = np.ascontiguousarray(stream_idx, dtype=np.int32)
+        ts = np.ascontiguousarray(timestamps, dtype=np.float64)
+        g = np.ascontiguousarray(gyro, dtype=np.float64).reshape(-1, 3)
+        assert len(si) == len(ts) == len(g)
+        N.check(N.lib().av_frontend_push_imu_batch(self._h, si.ctypes.data_as(C.c_void_p), ts.ctypes.data_as(C.c_void_p),
+                                                   g.ctypes.data_as(C.c_void_p), len(si)))
+
     def step(self, img0, img1, timestamps):
         """img0/img1: uint8 cuda tensors [S,h,w] (contiguous); timestamps: S floats.  Enqueues only."""
         S = self.n_streams
@@ -142,3 +151,16 @@ class FrontendEngine(object):
         with torch.cuda.device(self.device):
             N.check(N.lib().av_frontend_read_counters(self._h, int(stream), C.byref(out), self._stream()))
         return dict(zip(COUNTER_NAMES, [int(v) for v in out]))
+
+    def enable_timing(self, max_spans):
+        """Bracket every launch group with HIP events on the step's stream (bench roofline leg)."""
+        N.check(N.lib().av_frontend_enable_timing(self._h, int(max_spans)))
+
+    def read_timing(self):
+        """{class: (total_ms, n_launch_groups)} since the last read; synchronises the device."""
+        ms = (C.c_double * 4)(); n = (C.c_int32 * 4)()
+        N.check(N.lib().av_frontend_read_timing(self._h, C.byref(ms), C.byref(n)))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(('pyramid', 'lk', 'fast', 'glue'))}
+
+    def read_all_counters(self):
+        return [self.read_counters(s) for s in range(self.n_streams)]
