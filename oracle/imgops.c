@@ -122,6 +122,10 @@ static inline int cv_floor_f(float v) { return (int)floorf(v); }
 
 #define LK_MAX_WIN 31
 
+/* debug statistics of the last orc_lk_track call: [0] level passes that built an I patch,
+ * [1] Newton iterations, [2] points */
+ORC_API long long orc_lk_stats[3];
+
 /* ------------------------------------------------------------------------------------------
  * calcOpticalFlowPyrLK with OPTFLOW_USE_INITIAL_FLOW (always set by the reference,
  * config.py:44), minEigThreshold = 1e-4 (the OpenCV default; the reference does not pass it).
@@ -143,6 +147,7 @@ ORC_API void orc_lk_track(int nlev, const uint8_t* const* pyrI, const uint8_t* c
     if (win > LK_MAX_WIN) return;
 
     for (int i = 0; i < n; ++i) status[i] = 1;
+    orc_lk_stats[0] = orc_lk_stats[1] = 0; orc_lk_stats[2] = n;
 
     short Iw[LK_MAX_WIN * LK_MAX_WIN], Ix[LK_MAX_WIN * LK_MAX_WIN], Iy[LK_MAX_WIN * LK_MAX_WIN];
 
@@ -173,6 +178,7 @@ ORC_API void orc_lk_track(int nlev, const uint8_t* const* pyrI, const uint8_t* c
             int iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
             int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
+            orc_lk_stats[0]++;
             int64_t sA11 = 0, sA12 = 0, sA22 = 0;
             for (int y = 0; y < win; ++y)
                 for (int x = 0; x < win; ++x) {
@@ -212,6 +218,7 @@ ORC_API void orc_lk_track(int nlev, const uint8_t* const* pyrI, const uint8_t* c
                 iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));
                 iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
                 iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+                orc_lk_stats[1]++;
                 int64_t sb1 = 0, sb2 = 0;
                 for (int y = 0; y < win; ++y)
                     for (int x = 0; x < win; ++x) {
