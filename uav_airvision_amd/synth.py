@@ -88,7 +88,7 @@ class SyntheticStream(object):
     """
 
     def __init__(self, config, seed=0, n_frames=20, t0=100.0, lead_in=1.0, motion_scale=1.0,
-                 pixel_noise=1.0, texture=None):
+                 pixel_noise=1.0, texture=None, render=True):
         self.config = config
         self.seed = int(seed)
         self.n_frames = int(n_frames)
@@ -97,7 +97,7 @@ class SyntheticStream(object):
         self.motion_scale = float(motion_scale)
         self.pixel_noise = float(pixel_noise)
         self.rng = np.random.default_rng(0xA1B0 + self.seed)
-        self.tex = make_texture(0xA1B0 + self.seed) if texture is None else texture
+        self.tex = (make_texture(0xA1B0 + self.seed) if texture is None else texture) if render else None
 
         # camera <-> imu geometry (T_imu_cam*: imu-frame vector -> camera frame)
         self.T_c0_i = np.linalg.inv(config.T_imu_cam0)      # cam0 -> imu
@@ -110,8 +110,9 @@ class SyntheticStream(object):
         self.wall_d = 5.2
         e1 = np.cross(self.wall_n, [0., 0., 1.]); self.wall_e1 = e1 / np.linalg.norm(e1)
         self.wall_e2 = np.cross(self.wall_n, self.wall_e1)
-        self.rays0 = _undistorted_rays(config.cam0_intrinsics, config.cam0_distortion_coeffs)
-        self.rays1 = _undistorted_rays(config.cam1_intrinsics, config.cam1_distortion_coeffs)
+        if render:
+            self.rays0 = _undistorted_rays(config.cam0_intrinsics, config.cam0_distortion_coeffs)
+            self.rays1 = _undistorted_rays(config.cam1_intrinsics, config.cam1_distortion_coeffs)
         self.imu = self._make_imu()
 
     # ---- trajectory ------------------------------------------------------------------------
@@ -202,3 +203,86 @@ def replay(stream, imu_sinks, on_frame):
                 sink(pending)
             pending = next(it, None)
         on_frame(msg)
+
+
+feature_msg_t = namedtuple('feature_msg', ['timestamp', 'features'])
+
+
+class _Meas(object):
+    __slots__ = ('id', 'u0', 'v0', 'u1', 'v1')
+
+
+class SyntheticFeatureStream(object):
+    """Stereo feature measurements (normalised coordinates) for the filter half, without images:
+    random landmarks in view of the moving stereo rig of a SyntheticStream, track length
+    U{3..24} frames, pixel noise sigma ~0.5 px (MSCKF microbench recipe).
+    `frames()` yields feature_msg(timestamp, [FeatureMeasurement-like]); `imu` as SyntheticStream."""
+
+    def __init__(self, config, seed=0, n_frames=100, n_features=100, pixel_sigma=0.5, motion_scale=1.0, t0=100.0):
+        self.base = SyntheticStream(config, seed=seed, n_frames=n_frames, motion_scale=motion_scale, t0=t0, render=False)
+        self.config = config
+        self.n_frames = n_frames
+        self.n_features = n_features
+        self.imu = self.base.imu
+        self.rng = np.random.default_rng(0xFEA7 + seed)
+        self.sigma = pixel_sigma / float(config.cam0_intrinsics[0])
+        self.T_c0_i = self.base.T_c0_i
+        self.T_c1_i = self.base.T_c1_i
+        self._next_id = 0
+        self._tracks = []            # [id, p_world, frames_left]
+        self._msgs = [self._make(k) for k in range(n_frames)]
+
+    def _spawn(self, R_c0_w, c0_w):
+        depth = self.rng.uniform(2.0, 8.0)
+        pc = np.array([self.rng.uniform(-0.6, 0.6), self.rng.uniform(-0.4, 0.4), 1.0]) * depth
+        tr = [self._next_id, R_c0_w @ pc + c0_w, int(self.rng.integers(3, 25))]
+        self._next_id += 1
+        return tr
+
+    def _make(self, k):
+        t = self.base.frame_time(k)
+        R_i_w, p = self.base.R_i_w(t), self.base.position(t)
+        R0, c0 = R_i_w @ self.T_c0_i[:3, :3], p + R_i_w @ self.T_c0_i[:3, 3]
+        R1, c1 = R_i_w @ self.T_c1_i[:3, :3], p + R_i_w @ self.T_c1_i[:3, 3]
+        self._tracks = [tr for tr in self._tracks if tr[2] > 0]
+        while len(self._tracks) < self.n_features:
+            self._tracks.append(self._spawn(R0, c0))
+        feats = []
+        for tr in self._tracks:
+            q0 = R0.T @ (tr[1] - c0)
+            q1 = R1.T @ (tr[1] - c1)
+            tr[2] -= 1
+            if q0[2] < 0.5 or q1[2] < 0.5 or abs(q0[0] / q0[2]) > 0.75 or abs(q0[1] / q0[2]) > 0.5:
+                tr[2] = 0
+                continue
+            n = self.rng.normal(0, self.sigma, 4)
+            m = _Meas()
+            m.id = tr[0]
+            m.u0, m.v0 = q0[0] / q0[2] + n[0], q0[1] / q0[2] + n[1]
+            m.u1, m.v1 = q1[0] / q1[2] + n[2], q1[1] / q1[2] + n[3]
+            feats.append(m)
+        return feature_msg_t(t, feats)
+
+    def frame(self, k):
+        return self._msgs[k]
+
+    def frames(self):
+        return iter(self._msgs)
+
+    def truth(self, k):
+        """(R_i_w, p_w) of the IMU at frame k."""
+        t = self.base.frame_time(k)
+        return self.base.R_i_w(t), self.base.position(t)
+
+
+def replay_features(fstream, imu_sinks, on_features):
+    """Deterministic replay for the filter: IMU with timestamp <= t first, then the feature message."""
+    it = iter(fstream.imu)
+    pending = next(it, None)
+    for k in range(fstream.n_frames):
+        msg = fstream.frame(k)
+        while pending is not None and pending.timestamp <= msg.timestamp:
+            for sink in imu_sinks:
+                sink(pending)
+            pending = next(it, None)
+        on_features(msg)
