@@ -172,6 +172,58 @@ int av_frontend_read_grid(av_frontend* fe, int stream_idx, int64_t* ids, int32_t
  * n_published, overflow_flags].  Synchronises. */
 int av_frontend_read_counters(av_frontend* fe, int stream_idx, int32_t out[8], void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * MSCKF back-end: the batched small-dense fp64 linear algebra of MSCKF.feature_callback
+ * (reference: msckf.py:177-228).  The covariance P lives on the device inside the context (row-major,
+ * leading dimension av_msckf_ld); state vectors and the feature/camera bookkeeping stay with the
+ * caller (the Python MSCKF class mirrors the reference's dict bookkeeping).  Per-feature inputs are
+ * CSR-style: observations of feature f are obs_off[f] .. obs_off[f+1]-1, each with the index of its
+ * camera state (position in the cam_states dict) and z = (u0, v0, u1, v1).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct av_msckf av_msckf;
+
+/* chi2_table_100[d] = chi2.ppf(0.05, d) for d = 1..99 (msckf.py:111-113); rows_cap = capacity of the
+ * stacked Jacobian in rows (the prune path of the reference is uncapped). */
+int  av_msckf_create(int max_cam_states, int rows_cap, const double* chi2_table_100, int device, av_msckf** out);
+void av_msckf_destroy(av_msckf* ctx);
+int  av_msckf_ld(const av_msckf* ctx);
+int  av_msckf_dim(const av_msckf* ctx);
+/* state_cov <- host matrix n x n (reset_state_cov msckf.py:788-798, online_reset :843); / read back. */
+int  av_msckf_set_cov(av_msckf* ctx, const double* P_host, int n, void* stream);
+int  av_msckf_get_cov(av_msckf* ctx, double* P_host, int n, void* stream);
+/* MSCKF.process_model covariance part (msckf.py:282-335) for one IMU sample: builds F, G, Phi (3rd
+ * order), applies the observability fix with the null-space states, Q = Phi G Qc G^T Phi^T dt,
+ * P11 <- Phi P11 Phi^T + Q, P12 <- Phi P12, symmetrise.  gyro/acc are bias-corrected; q_old is the
+ * orientation before predict_new_state, q_new/v_new/p_new after; noise = continuous variances
+ * [gyro, gyro_bias, acc, acc_bias] (msckf.py:123-127). */
+int  av_msckf_propagate(av_msckf* ctx, double dt, const double gyro[3], const double acc[3], const double q_old[4],
+                        const double q_new[4], const double q_null[4], const double v_null[3], const double p_null[3],
+                        const double v_new[3], const double p_new[3], const double gravity[3], const double noise[4],
+                        void* stream);
+/* MSCKF.state_augmentation covariance part (msckf.py:407-423): J = [R_i_c 0 0 0 0 I 0; skew(R_w_i^T t_c_i) 0 0 0 I 0 I]. */
+int  av_msckf_augment(av_msckf* ctx, const double R_imu_cam0[9], const double skew_Rt_t[9], void* stream);
+/* prune_cam_state_buffer (msckf.py:774-786): drop the 6 rows/cols of camera state #cam_index. */
+int  av_msckf_remove_cam(av_msckf* ctx, int cam_index, void* stream);
+/* Feature.initialize_position (feature/feature_position_initializer.py:6-76) for n_feat features.
+ * opt5 = [huber_epsilon, estimation_precision, initial_damping, outer_loop_max, inner_loop_max]
+ * (config.py:7-17); max_views = 2 * (largest observation count) <= 64. */
+int  av_msckf_triangulate(av_msckf* ctx, int n_feat, const int32_t* obs_off_dev, const int32_t* obs_cam_dev, const double* obs_z_dev,
+                          const double* cam_q_dev, const double* cam_p_dev, const double* T_cam0_cam1_rowmajor44,
+                          const double* opt5, int max_views, double* pos_dev, int32_t* valid_dev, void* stream);
+/* MSCKF.feature_jacobian + gating_test (msckf.py:509-546, 604-612) for n_feat features: writes the
+ * null-space-projected rows (4M-3 per feature, starting at row_off[f]) into the context's block
+ * buffer and gamma / pass per feature.  dof[f] = chi^2 degrees of freedom (msckf.py:662, 761). */
+int  av_msckf_feature_blocks(av_msckf* ctx, int n_feat, int n_cam, int max_obs, const int32_t* obs_off_dev, const int32_t* obs_cam_dev,
+                             const double* obs_z_dev, const double* pos_dev, const int32_t* dof_dev, const int32_t* row_off_dev, int total_rows,
+                             const double* cam_q_dev, const double* cam_p_dev, const double* cam_qn_dev, const double* cam_pn_dev,
+                             const double* T_cam0_cam1_rowmajor44, const double gravity[3], double obs_noise,
+                             double* gamma_dev, int32_t* pass_dev, void* stream);
+/* MSCKF.measurement_update (msckf.py:548-602) on the blocks (first row, length) selected by the
+ * caller after gating: thin QR when rows > n, S, gain, P <- sym((I-KH)P).  Synchronises and returns
+ * delta_x (n doubles) for the caller's state injection (msckf.py:568-595). */
+int  av_msckf_update(av_msckf* ctx, const int32_t* blk_row_dev, const int32_t* blk_len_dev, int n_blk, int total_rows,
+                     double obs_noise, double* dx_host, void* stream);
+
 /* Measurement hooks (bench.py's roofline leg; no reference counterpart): when enabled, every
  * launch group of av_frontend_step is bracketed by a HIP event pair ON THE STEP'S STREAM.
  * max_spans = capacity in event pairs (0 disables).  av_frontend_read_timing synchronises the

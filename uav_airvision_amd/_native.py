@@ -67,6 +67,19 @@ SIGNATURES = {
     'av_frontend_read_features': (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
     'av_frontend_read_grid': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64), _P]),
     'av_frontend_read_counters': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32 * 8), _P]),
+    'av_msckf_create': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(_P)]),
+    'av_msckf_destroy': (None, [_P]),
+    'av_msckf_ld': (C.c_int, [_P]),
+    'av_msckf_dim': (C.c_int, [_P]),
+    'av_msckf_set_cov': (C.c_int, [_P, _P, C.c_int, _P]),
+    'av_msckf_get_cov': (C.c_int, [_P, _P, C.c_int, _P]),
+    'av_msckf_propagate': (C.c_int, [_P, C.c_double] + [C.POINTER(C.c_double)] * 11 + [_P]),
+    'av_msckf_augment': (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
+    'av_msckf_remove_cam': (C.c_int, [_P, C.c_int, _P]),
+    'av_msckf_triangulate': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, _P, _P, _P]),
+    'av_msckf_feature_blocks': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, _P, _P, _P]),
+    'av_msckf_update': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P]),
     'av_frontend_enable_timing': (C.c_int, [_P, C.c_int]),
     'av_frontend_read_timing': (C.c_int, [_P, C.POINTER(C.c_double * 4), C.POINTER(C.c_int32 * 4)]),
 }

@@ -1,0 +1,999 @@
+// msckf.hip -- the MSCKF measurement update's batched small-dense fp64 linear algebra (gfx950).
+//
+// Reference being replaced (src/msckf.py unless noted), SURVEY.md section 8(a) rows a14-a25:
+//   process_model:275-339          F, G, 3rd-order Phi, OC-KF fix, P <- Phi P Phi^T + Q, cross terms   -> propagate_kernel
+//   state_augmentation:390-423     P grows by the 6x21 Jacobian J                                      -> augment_kernel
+//   feature/feature_position_initializer.py:6-76 (+ feature_observation.py, feature_depth_estimator.py)
+//                                  Levenberg-Marquardt triangulation in (alpha, beta, rho)             -> triangulate_kernel
+//   measurement_jacobian:443-507, feature_jacobian:509-546, gating_test:604-612
+//                                  per-feature 4x6 / 4x3 blocks, null-space projection, chi^2 gate     -> feature_kernel
+//   measurement_update:548-602     thin QR (m > n), S = H P H^T + s^2 I, K, delta_x, P <- (I-KH)P, sym -> update_kernel
+//   prune_cam_state_buffer:774-786 delete 6 rows/cols per removed camera state                         -> remove_cam_kernel
+//
+// The reference uses numpy/LAPACK: full SVD of H_f for the null space (msckf.py:540), Householder
+// QR (msckf.py:555) and LU solves (msckf.py:565,607).  Here: Householder QR of H_f (3 reflectors;
+// any orthonormal basis of the left null space gives the same gamma, delta_x and P -- SURVEY 8a
+// "invariants"), Householder QR for the compression, Cholesky for the SPD solves.  fp64 everywhere;
+// parity with the reference is to tolerance (stated in tests/test_gpu_msckf.py), not bitwise.
+//
+// MI355X mapping: one wavefront per feature for triangulation (views across lanes, butterfly
+// reductions); one 256-thread workgroup per feature for the Jacobian/projection/gate with the
+// (4M x 6M) block and the (4M-3)^2 innovation covariance in LDS (sized by the largest track in the
+// batch); one 1024-thread workgroup for the stacked update, matrices <= 141x141 in L2-resident
+// scratch with the Cholesky factor packed in LDS (80 KB).  MFMA is not used: the only dense
+// contraction is <= 141^3 and is latency-, not throughput-bound at this size.
+#include <math.h>
+
+#include <new>
+#include <vector>
+
+#include "av_common.h"
+
+namespace {
+
+constexpr int IMU_DIM = 21;
+
+__device__ __forceinline__ void quat_to_rot(const double* qin, double* R)
+{
+    // utils.py:12-23: normalise, R = (2w^2-1) I - 2w [v]x + 2 v v^T
+    double n = sqrt(qin[0] * qin[0] + qin[1] * qin[1] + qin[2] * qin[2] + qin[3] * qin[3]);
+    double x = qin[0] / n, y = qin[1] / n, z = qin[2] / n, w = qin[3] / n;
+    double c = 2 * w * w - 1;
+    R[0] = c + 2 * x * x;          R[1] = 2 * w * z + 2 * x * y;   R[2] = -2 * w * y + 2 * x * z;
+    R[3] = -2 * w * z + 2 * y * x; R[4] = c + 2 * y * y;           R[5] = 2 * w * x + 2 * y * z;
+    R[6] = 2 * w * y + 2 * z * x;  R[7] = -2 * w * x + 2 * z * y;  R[8] = c + 2 * z * z;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// ================================================================================================
+// Triangulation: one wavefront per feature, lane = view (obs j, camera c) with view = 2j + c.
+// ================================================================================================
+struct TriArgs {
+    int n_feat;
+    const int* obs_off;          // [n_feat + 1]
+    const int* obs_cam;          // camera-state index of every observation
+    const double* obs_z;         // [.][4] = u0 v0 u1 v1
+    const double* cam_q;         // [n_cam][4]
+    const double* cam_p;         // [n_cam][3]
+    double R01[9], t01[3];       // cam0 -> cam1 (config.T_cn_cnm1)
+    double huber, precision, damping;
+    int outer_max, inner_max;
+    double* out_pos;             // [n_feat][3] world position
+    int* out_valid;              // [n_feat]
+};
+
+__device__ __forceinline__ void solve3(const double A[9], const double b[3], double x[3])
+{
+    // Gaussian elimination with partial pivoting (what np.linalg.solve's gesv does)
+    double M[3][4] = {{A[0], A[1], A[2], b[0]}, {A[3], A[4], A[5], b[1]}, {A[6], A[7], A[8], b[2]}};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int piv = k;
+        double best = fabs(M[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < 3; ++i) if (fabs(M[i][k]) > best) { best = fabs(M[i][k]); piv = i; }
+        if (piv != k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { double t = M[k][j]; M[k][j] = M[piv][j]; M[piv][j] = t; }
+#pragma unroll
+        for (int i = k + 1; i < 3; ++i) {
+            double f = M[i][k] / M[k][k];
+#pragma unroll
+            for (int j = k; j < 4; ++j) M[i][j] -= f * M[k][j];
+        }
+    }
+    x[2] = M[2][3] / M[2][2];
+    x[1] = (M[1][3] - M[1][2] * x[2]) / M[1][1];
+    x[0] = (M[0][3] - M[0][1] * x[1] - M[0][2] * x[2]) / M[0][0];
+}
+
+__global__ __launch_bounds__(256) void triangulate_kernel(TriArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= a.n_feat) return;
+    const int o0 = a.obs_off[f], M = a.obs_off[f + 1] - o0;
+    const int nv = 2 * M;                                   // views; host guarantees nv <= 64
+    const bool act = lane < nv;
+    const int j = act ? (lane >> 1) : 0, cam = lane & 1;
+
+    // pose of this view (camera -> world), feature_position_initializer.py:19-26
+    double Rv[9], tv[3], z[2] = {0, 0};
+    {
+        const int ci = a.obs_cam[o0 + j];
+        double Rwc[9];
+        quat_to_rot(a.cam_q + 4 * ci, Rwc);                 // world -> cam0
+        double R0[9];                                       // cam0 -> world = Rwc^T
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) R0[r * 3 + c] = Rwc[c * 3 + r];
+        const double* p = a.cam_p + 3 * ci;
+        if (cam == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rv[i] = R0[i];
+            tv[0] = p[0]; tv[1] = p[1]; tv[2] = p[2];
+        } else {
+            // cam1 pose = cam0 * inverse(T_cam0_cam1): R = R0 * R01^T, t = R0 * (-R01^T t01) + p
+            double t10[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) t10[r] = -(a.R01[0 * 3 + r] * a.t01[0] + a.R01[1 * 3 + r] * a.t01[1] + a.R01[2 * 3 + r] * a.t01[2]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Rv[r * 3 + c] = R0[r * 3 + 0] * a.R01[c * 3 + 0] + R0[r * 3 + 1] * a.R01[c * 3 + 1] + R0[r * 3 + 2] * a.R01[c * 3 + 2];
+                tv[r] = R0[r * 3 + 0] * t10[0] + R0[r * 3 + 1] * t10[1] + R0[r * 3 + 2] * t10[2] + p[r];
+            }
+        }
+        z[0] = a.obs_z[4 * (o0 + j) + 2 * cam];
+        z[1] = a.obs_z[4 * (o0 + j) + 2 * cam + 1];
+    }
+    // first view's pose (T_c0_w) broadcast, then relative pose  inv(pose_v) * pose_0
+    double R00[9], t00[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R00[i] = __shfl(Rv[i], 0, 64);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t00[i] = __shfl(tv[i], 0, 64);
+    double R[9], t[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[r * 3 + c] = Rv[0 * 3 + r] * R00[0 * 3 + c] + Rv[1 * 3 + r] * R00[1 * 3 + c] + Rv[2 * 3 + r] * R00[2 * 3 + c];
+        t[r] = Rv[0 * 3 + r] * (t00[0] - tv[0]) + Rv[1 * 3 + r] * (t00[1] - tv[1]) + Rv[2 * 3 + r] * (t00[2] - tv[2]);
+    }
+
+    // two-view initial guess from views 0 and 1 (feature_depth_estimator.py:4-14)
+    double x[3];
+    {
+        double R1[9], t1[3], z0[2], z1[2];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R1[i] = __shfl(R[i], 1, 64);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t1[i] = __shfl(t[i], 1, 64);
+        z0[0] = __shfl(z[0], 0, 64); z0[1] = __shfl(z[1], 0, 64);
+        z1[0] = __shfl(z[0], 1, 64); z1[1] = __shfl(z[1], 1, 64);
+        double m[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) m[r] = R1[r * 3 + 0] * z0[0] + R1[r * 3 + 1] * z0[1] + R1[r * 3 + 2];
+        double a0 = m[0] - z1[0] * m[2], a1 = m[1] - z1[1] * m[2];
+        double b0 = z1[0] * t1[2] - t1[0], b1 = z1[1] * t1[2] - t1[1];
+        double depth = (a0 * b0 + a1 * b1) / (a0 * a0 + a1 * a1);
+        double p0[3] = {z0[0] * depth, z0[1] * depth, depth};
+        x[0] = p0[0] / p0[2]; x[1] = p0[1] / p0[2]; x[2] = 1.0 / p0[2];
+    }
+
+    auto cost_of = [&](const double* xx) -> double {
+        double h0 = R[0] * xx[0] + R[1] * xx[1] + R[2] + xx[2] * t[0];
+        double h1 = R[3] * xx[0] + R[4] * xx[1] + R[5] + xx[2] * t[1];
+        double h2 = R[6] * xx[0] + R[7] * xx[1] + R[8] + xx[2] * t[2];
+        double d0 = h0 / h2 - z[0], d1 = h1 / h2 - z[1];
+        return wave_sum_f64(act ? d0 * d0 + d1 * d1 : 0.0);
+    };
+
+    double lam = a.damping;
+    int outer = 0, inner = 0;
+    double delta_norm = INFINITY;
+    double total = cost_of(x);
+    while (outer < a.outer_max && delta_norm > a.precision) {
+        // J (2x3), r (2), Huber weight (feature_observation.py:14-39)
+        double h0 = R[0] * x[0] + R[1] * x[1] + R[2] + x[2] * t[0];
+        double h1 = R[3] * x[0] + R[4] * x[1] + R[5] + x[2] * t[1];
+        double h2 = R[6] * x[0] + R[7] * x[1] + R[8] + x[2] * t[2];
+        double W0[3] = {R[0], R[1], t[0]}, W1[3] = {R[3], R[4], t[1]}, W2[3] = {R[6], R[7], t[2]};
+        double J0[3], J1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            J0[c] = W0[c] / h2 - W2[c] * h0 / (h2 * h2);
+            J1[c] = W1[c] / h2 - W2[c] * h1 / (h2 * h2);
+        }
+        double r0 = h0 / h2 - z[0], r1 = h1 / h2 - z[1];
+        double e = sqrt(r0 * r0 + r1 * r1);
+        double w = (e <= a.huber) ? 1.0 : a.huber / (2 * e);
+        double ww = (w == 1.0) ? 1.0 : w * w;
+        if (!act) ww = 0.0;
+        double A[9], b[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) A[r * 3 + c] = wave_sum_f64(ww * (J0[r] * J0[c] + J1[r] * J1[c]));
+            b[r] = wave_sum_f64(ww * (J0[r] * r0 + J1[r] * r1));
+        }
+        bool reduced = false;
+        while (inner < a.inner_max && !reduced) {
+            double Ad[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Ad[i] = A[i] + ((i % 4 == 0) ? lam : 0.0);
+            double d[3];
+            solve3(Ad, b, d);
+            double xn[3] = {x[0] - d[0], x[1] - d[1], x[2] - d[2]};
+            delta_norm = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            double cn = cost_of(xn);
+            if (cn < total) {
+                reduced = true;
+                x[0] = xn[0]; x[1] = xn[1]; x[2] = xn[2];
+                total = cn;
+                lam = fmax(lam / 10., 1e-10);
+            } else {
+                lam = fmin(lam * 10., 1e12);
+            }
+            ++inner;
+        }
+        ++outer;
+    }
+    double pf[3] = {x[0] / x[2], x[1] / x[2], 1.0 / x[2]};
+    double depth_v = R[6] * pf[0] + R[7] * pf[1] + R[8] * pf[2] + t[2];
+    unsigned long long bad = __ballot(act && !(depth_v > 0));
+    if (lane == 0) {
+        // position in the world: T_c0_w.R @ pf + T_c0_w.t (this lane is view 0, so Rv/tv = T_c0_w)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) a.out_pos[3 * f + r] = Rv[r * 3 + 0] * pf[0] + Rv[r * 3 + 1] * pf[1] + Rv[r * 3 + 2] * pf[2] + tv[r];
+        a.out_valid[f] = bad == 0ull ? 1 : 0;
+    }
+}
+
+// ================================================================================================
+// Per-feature Jacobian, null-space projection and chi^2 gate: one 256-thread workgroup per feature.
+// ================================================================================================
+struct FeatArgs {
+    int n_feat, n_cam, ld;               // ld = leading dimension of P and of the output rows (>= 21 + 6 n_cam)
+    const int* obs_off; const int* obs_cam; const double* obs_z;
+    const double* pos;                   // [n_feat][3]
+    const int* dof;                      // chi^2 degrees of freedom per feature (msckf.py:662,761)
+    const int* row_off;                  // first output row of each feature (prefix of 4M-3)
+    const double* cam_q; const double* cam_p; const double* cam_qn; const double* cam_pn;
+    const double* P;                     // [n][ld]
+    const double* chi2;                  // chi2.ppf(0.05, dof), index dof (1..99)
+    double R01[9], t01[3], gravity[3], obs_noise;
+    double* Hout;                        // [rows][ld]
+    double* rout;                        // [rows]
+    double* gamma; int* pass;            // [n_feat]
+    int Mmax;
+};
+
+__global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
+{
+    extern __shared__ double sm[];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int o0 = a.obs_off[f], M = a.obs_off[f + 1] - o0;
+    const int R4 = 4 * M, C6 = 6 * M, K = R4 - 3;
+    const int Mx = a.Mmax;
+    double* H = sm;                              // [4Mx][6Mx]  row-major, stride C6
+    double* Hf = H + (4 * Mx) * (6 * Mx);        // [4Mx][3]
+    double* rr = Hf + (4 * Mx) * 3;              // [4Mx]
+    double* S = rr + 4 * Mx;                     // [4Mx][4Mx]
+    double* Tc = S + (4 * Mx) * (4 * Mx);        // [8][6Mx]
+    double* red = Tc + 8 * (6 * Mx);             // [256] reduction scratch
+    int* cidx = reinterpret_cast<int*>(red + 256);   // [Mx] camera index per observation
+
+    for (int i = tid; i < R4 * C6; i += 256) H[i] = 0.0;
+    for (int i = tid; i < M; i += 256) cidx[i] = a.obs_cam[o0 + i];
+    __syncthreads();
+
+    // ---- measurement_jacobian per observation (msckf.py:443-507): thread j < M ---------------------
+    if (tid < M) {
+        const int j = tid, ci = a.obs_cam[o0 + j];
+        double Rw0[9], Rw1[9];
+        quat_to_rot(a.cam_q + 4 * ci, Rw0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Rw1[r * 3 + c] = a.R01[r * 3 + 0] * Rw0[0 * 3 + c] + a.R01[r * 3 + 1] * Rw0[1 * 3 + c] + a.R01[r * 3 + 2] * Rw0[2 * 3 + c];
+        const double* t0 = a.cam_p + 3 * ci;
+        double t1[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) t1[r] = t0[r] - (Rw1[0 * 3 + r] * a.t01[0] + Rw1[1 * 3 + r] * a.t01[1] + Rw1[2 * 3 + r] * a.t01[2]);
+        const double* pw = a.pos + 3 * f;
+        double d0[3] = {pw[0] - t0[0], pw[1] - t0[1], pw[2] - t0[2]}, d1[3] = {pw[0] - t1[0], pw[1] - t1[1], pw[2] - t1[2]};
+        double p0[3], p1[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            p0[r] = Rw0[r * 3] * d0[0] + Rw0[r * 3 + 1] * d0[1] + Rw0[r * 3 + 2] * d0[2];
+            p1[r] = Rw1[r * 3] * d1[0] + Rw1[r * 3 + 1] * d1[1] + Rw1[r * 3 + 2] * d1[2];
+        }
+        // dz/dp (rows 0,1 from cam0, rows 2,3 from cam1)
+        double dz[4][3] = {{1 / p0[2], 0, -p0[0] / (p0[2] * p0[2])}, {0, 1 / p0[2], -p0[1] / (p0[2] * p0[2])},
+                           {1 / p1[2], 0, -p1[0] / (p1[2] * p1[2])}, {0, 1 / p1[2], -p1[1] / (p1[2] * p1[2])}};
+        double sk[9] = {0, -p0[2], p0[1], p0[2], 0, -p0[0], -p0[1], p0[0], 0};
+        double dp0[3][6], dp1[3][6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                dp0[r][c] = sk[r * 3 + c];
+                dp0[r][3 + c] = -Rw0[r * 3 + c];
+                dp1[r][c] = a.R01[r * 3 + 0] * sk[0 * 3 + c] + a.R01[r * 3 + 1] * sk[1 * 3 + c] + a.R01[r * 3 + 2] * sk[2 * 3 + c];
+                dp1[r][3 + c] = -Rw1[r * 3 + c];
+            }
+        double A[4][6];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double(*dp)[6] = r < 2 ? dp0 : dp1;
+                A[r][c] = dz[r][0] * dp[0][c] + dz[r][1] * dp[1][c] + dz[r][2] * dp[2][c];
+            }
+        // observability-constrained projection with the null-space states
+        double Rn[9], u[6];
+        quat_to_rot(a.cam_qn + 4 * ci, Rn);
+        const double* g = a.gravity;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) u[r] = Rn[r * 3] * g[0] + Rn[r * 3 + 1] * g[1] + Rn[r * 3 + 2] * g[2];
+        const double* pn = a.cam_pn + 3 * ci;
+        double e[3] = {pw[0] - pn[0], pw[1] - pn[1], pw[2] - pn[2]};
+        u[3] = -e[2] * g[1] + e[1] * g[2];
+        u[4] = e[2] * g[0] - e[0] * g[2];
+        u[5] = -e[1] * g[0] + e[0] * g[1];
+        double uu = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) uu += u[c] * u[c];
+        const double* zz = a.obs_z + 4 * (o0 + j);
+        double zh[4] = {p0[0] / p0[2], p0[1] / p0[2], p1[0] / p1[2], p1[1] / p1[2]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double Au = 0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Au += A[r][c] * u[c];
+            double hx[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { hx[c] = A[r][c] - Au * u[c] / uu; H[(4 * j + r) * C6 + 6 * j + c] = hx[c]; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Hf[(4 * j + r) * 3 + c] = -hx[3 + c];
+            rr[4 * j + r] = zz[r] - zh[r];
+        }
+    }
+    __syncthreads();
+
+    // ---- left null space of H_f by 3 Householder reflectors, applied to H and r (msckf.py:540-544) --
+    for (int k = 0; k < 3; ++k) {
+        // norm of Hf[k:, k]
+        double part = 0;
+        for (int i = k + tid; i < R4; i += 256) { double v = Hf[i * 3 + k]; part += v * v; }
+        red[tid] = part;
+        __syncthreads();
+        for (int s2 = 128; s2 > 0; s2 >>= 1) { if (tid < s2) red[tid] += red[tid + s2]; __syncthreads(); }
+        const double nrm = sqrt(red[0]);
+        __syncthreads();
+        const double akk = Hf[k * 3 + k];
+        const double alpha = akk >= 0 ? -nrm : nrm;
+        const double v0 = akk - alpha;                     // v = x - alpha e1, stored in place in Hf[k:, k] (v0 kept apart)
+        const double vtv = nrm * nrm - 2 * alpha * akk + alpha * alpha;      // |v|^2
+        const double tau = vtv > 0 ? 2.0 / vtv : 0.0;
+        // columns to transform: remaining Hf columns (k+1..2), all C6 columns of H, and r  => C6 + (2-k) + 1 jobs
+        const int njobs = C6 + (2 - k) + 1;
+        for (int job = tid; job < njobs; job += 256) {
+            double* col; int stride;
+            if (job < C6) { col = H + job; stride = C6; }
+            else if (job < C6 + (2 - k)) { col = Hf + (k + 1 + job - C6); stride = 3; }
+            else { col = rr; stride = 1; }
+            double dot = v0 * col[k * stride];
+            for (int i = k + 1; i < R4; ++i) dot += Hf[i * 3 + k] * col[i * stride];
+            dot *= tau;
+            col[k * stride] -= dot * v0;
+            for (int i = k + 1; i < R4; ++i) col[i * stride] -= dot * Hf[i * 3 + k];
+        }
+        __syncthreads();
+    }
+    // rows 3..R4-1 of H and r are A^T H_x and A^T r.  Write them out (dense row of width ld).
+    const int row0 = a.row_off[f];
+    const int n = IMU_DIM + 6 * a.n_cam;
+    for (int i = tid; i < K * a.ld; i += 256) {
+        const int rI = i / a.ld, c = i - rI * a.ld;
+        a.Hout[(size_t)(row0 + rI) * a.ld + c] = 0.0;
+    }
+    __syncthreads();
+    for (int i = tid; i < K * C6; i += 256) {
+        const int rI = i / C6, c = i - rI * C6;
+        a.Hout[(size_t)(row0 + rI) * a.ld + IMU_DIM + 6 * cidx[c / 6] + c % 6] = H[(3 + rI) * C6 + c];
+    }
+    for (int i = tid; i < K; i += 256) a.rout[row0 + i] = rr[3 + i];
+    (void)n;
+
+    // ---- gating test (msckf.py:604-612): S = H' Psub H'^T + s^2 I, gamma = r'^T S^-1 r' -------------
+    for (int i0 = 0; i0 < K; i0 += 8) {
+        const int nr = min(8, K - i0);
+        __syncthreads();
+        for (int e = tid; e < nr * C6; e += 256) {
+            const int ri = e / C6, d = e - ri * C6;
+            const double* hrow = H + (3 + i0 + ri) * C6;
+            const int pd = IMU_DIM + 6 * cidx[d / 6] + d % 6;
+            double acc = 0;
+            for (int c = 0; c < C6; ++c) acc += hrow[c] * a.P[(size_t)(IMU_DIM + 6 * cidx[c / 6] + c % 6) * a.ld + pd];
+            Tc[ri * C6 + d] = acc;
+        }
+        __syncthreads();
+        for (int e = tid; e < nr * K; e += 256) {
+            const int ri = e / K, jj = e - ri * K;
+            const double* hrow = H + (3 + jj) * C6;
+            double acc = 0;
+            for (int d = 0; d < C6; ++d) acc += Tc[ri * C6 + d] * hrow[d];
+            S[(i0 + ri) * K + jj] = acc + ((i0 + ri) == jj ? a.obs_noise : 0.0);
+        }
+    }
+    __syncthreads();
+    // Cholesky S = L L^T (lower, in place) and forward solve L y = r'
+    for (int k = 0; k < K; ++k) {
+        if (tid == 0) S[k * K + k] = sqrt(S[k * K + k]);
+        __syncthreads();
+        const double dkk = S[k * K + k];
+        for (int i = k + 1 + tid; i < K; i += 256) S[i * K + k] /= dkk;
+        __syncthreads();
+        const int rem = K - k - 1;
+        for (int e = tid; e < rem * rem; e += 256) {
+            const int i = k + 1 + e / rem, jj = k + 1 + e % rem;
+            if (jj <= i) S[i * K + jj] -= S[i * K + k] * S[jj * K + k];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double g = 0;
+        for (int i = 0; i < K; ++i) {
+            double v = rr[3 + i];
+            for (int jj = 0; jj < i; ++jj) v -= S[i * K + jj] * red[jj];
+            v /= S[i * K + i];
+            red[i] = v;                          // K <= 77 < 256
+            g += v * v;
+        }
+        a.gamma[f] = g;
+        a.pass[f] = g < a.chi2[a.dof[f]] ? 1 : 0;
+    }
+}
+
+// ================================================================================================
+// Covariance propagation for one IMU sample (msckf.py:275-339, covariance part), one workgroup.
+// ================================================================================================
+struct PropArgs {
+    double* P; int n, ld;
+    double dt;
+    double gyro[3], acc[3];          // bias-corrected
+    double q_old[4];                 // orientation before predict_new_state (for F, G)
+    double q_new[4];                 // orientation after
+    double q_null[4], v_null[3], p_null[3];
+    double v_new[3], p_new[3];
+    double gravity[3];
+    double noise[4];                 // gyro, gyro_bias, acc, acc_bias (continuous)
+};
+
+__global__ __launch_bounds__(256) void propagate_kernel(PropArgs a)
+{
+    __shared__ double F[IMU_DIM * IMU_DIM], F2[IMU_DIM * IMU_DIM], Phi[IMU_DIM * IMU_DIM], G[IMU_DIM * 12], T[IMU_DIM * IMU_DIM], Q[IMU_DIM * IMU_DIM];
+    __shared__ double Rwi[9], Rnull[9], Rnew[9], u[3], sv[3], w1[3], w2[3];
+    const int tid = threadIdx.x;
+    const int N = IMU_DIM;
+    for (int i = tid; i < N * N; i += 256) F[i] = 0.0;
+    for (int i = tid; i < N * 12; i += 256) G[i] = 0.0;
+    if (tid == 0) { quat_to_rot(a.q_old, Rwi); quat_to_rot(a.q_null, Rnull); quat_to_rot(a.q_new, Rnew); }
+    __syncthreads();
+    if (tid == 0) {
+        const double* w = a.gyro; const double* ac = a.acc;
+        double skw[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+        double ska[9] = {0, -ac[2], ac[1], ac[2], 0, -ac[0], -ac[1], ac[0], 0};
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                F[r * N + c] = -skw[r * 3 + c];
+                F[r * N + 3 + c] = r == c ? -1.0 : 0.0;
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += Rwi[k * 3 + r] * ska[k * 3 + c];          // R^T skew(acc)
+                F[(6 + r) * N + c] = -s;
+                F[(6 + r) * N + 9 + c] = -Rwi[c * 3 + r];
+                F[(12 + r) * N + 6 + c] = r == c ? 1.0 : 0.0;
+                G[r * 12 + c] = r == c ? -1.0 : 0.0;
+                G[(3 + r) * 12 + 3 + c] = r == c ? 1.0 : 0.0;
+                G[(6 + r) * 12 + 6 + c] = -Rwi[c * 3 + r];
+                G[(9 + r) * 12 + 9 + c] = r == c ? 1.0 : 0.0;
+            }
+        for (int r = 0; r < 3; ++r) u[r] = Rnull[r * 3] * a.gravity[0] + Rnull[r * 3 + 1] * a.gravity[1] + Rnull[r * 3 + 2] * a.gravity[2];
+        double uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+        for (int r = 0; r < 3; ++r) sv[r] = u[r] / uu;
+        double dv[3] = {a.v_null[0] - a.v_new[0], a.v_null[1] - a.v_new[1], a.v_null[2] - a.v_new[2]};
+        double dp[3] = {a.dt * a.v_null[0] + a.p_null[0] - a.p_new[0], a.dt * a.v_null[1] + a.p_null[1] - a.p_new[1], a.dt * a.v_null[2] + a.p_null[2] - a.p_new[2]};
+        const double* g = a.gravity;
+        w1[0] = -dv[2] * g[1] + dv[1] * g[2]; w1[1] = dv[2] * g[0] - dv[0] * g[2]; w1[2] = -dv[1] * g[0] + dv[0] * g[1];
+        w2[0] = -dp[2] * g[1] + dp[1] * g[2]; w2[1] = dp[2] * g[0] - dp[0] * g[2]; w2[2] = -dp[1] * g[0] + dp[0] * g[1];
+    }
+    __syncthreads();
+    for (int i = tid; i < N * N; i += 256) F[i] *= a.dt;                       // Fdt
+    __syncthreads();
+    for (int i = tid; i < N * N; i += 256) {                                    // Fdt^2
+        int r = i / N, c = i - r * N; double s = 0;
+        for (int k = 0; k < N; ++k) s += F[r * N + k] * F[k * N + c];
+        F2[i] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < N * N; i += 256) {                                    // Fdt^3, Phi
+        int r = i / N, c = i - r * N; double s = 0;
+        for (int k = 0; k < N; ++k) s += F2[r * N + k] * F[k * N + c];
+        Phi[i] = (r == c ? 1.0 : 0.0) + F[i] + F2[i] / 2. + s / 6.;
+    }
+    __syncthreads();
+    if (tid < 9) {                                                              // Phi[:3,:3] = R_new R_null^T
+        int r = tid / 3, c = tid % 3; double s = 0;
+        for (int k = 0; k < 3; ++k) s += Rnew[r * 3 + k] * Rnull[c * 3 + k];
+        T[tid] = s;
+    }
+    __syncthreads();
+    if (tid < 9) Phi[(tid / 3) * N + tid % 3] = T[tid];
+    __syncthreads();
+    if (tid < 6) {                                                              // OC-KF corrections of rows 6..8 and 12..14
+        int blk = tid / 3, r = tid % 3;
+        int row = (blk == 0 ? 6 : 12) + r;
+        const double* wv = blk == 0 ? w1 : w2;
+        double Au = Phi[row * N] * u[0] + Phi[row * N + 1] * u[1] + Phi[row * N + 2] * u[2];
+        double d = Au - wv[r];
+        for (int c = 0; c < 3; ++c) T[tid * 3 + c] = Phi[row * N + c] - d * sv[c];
+    }
+    __syncthreads();
+    if (tid < 6) {
+        int row = (tid / 3 == 0 ? 6 : 12) + tid % 3;
+        for (int c = 0; c < 3; ++c) Phi[row * N + c] = T[tid * 3 + c];
+    }
+    __syncthreads();
+    // Q = Phi G Qc G^T Phi^T dt : T = Phi G (21x12)
+    for (int i = tid; i < N * 12; i += 256) {
+        int r = i / 12, c = i - r * 12; double s = 0;
+        for (int k = 0; k < N; ++k) s += Phi[r * N + k] * G[k * 12 + c];
+        T[i] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < N * N; i += 256) {
+        int r = i / N, c = i - r * N; double s = 0;
+        for (int k = 0; k < 12; ++k) s += T[r * 12 + k] * a.noise[k / 3] * T[c * 12 + k];
+        Q[i] = s * a.dt;
+    }
+    __syncthreads();
+    // P11 <- Phi P11 Phi^T + Q
+    for (int i = tid; i < N * N; i += 256) {
+        int r = i / N, c = i - r * N; double s = 0;
+        for (int k = 0; k < N; ++k) s += Phi[r * N + k] * a.P[(size_t)k * a.ld + c];
+        F2[i] = s;                                                              // Phi P11
+    }
+    __syncthreads();
+    for (int i = tid; i < N * N; i += 256) {
+        int r = i / N, c = i - r * N; double s = 0;
+        for (int k = 0; k < N; ++k) s += F2[r * N + k] * Phi[c * N + k];
+        F[i] = s + Q[i];
+    }
+    __syncthreads();
+    // P12 <- Phi P12 (computed from the OLD P12 into scratch rows of T in chunks), P21 = P12^T
+    const int nc = a.n - N;
+    for (int c0 = 0; c0 < nc; c0 += N) {
+        const int w = min(N, nc - c0);
+        for (int i = tid; i < N * w; i += 256) {
+            int r = i / w, c = i - r * w; double s = 0;
+            for (int k = 0; k < N; ++k) s += Phi[r * N + k] * a.P[(size_t)k * a.ld + N + c0 + c];
+            T[i] = s;
+        }
+        __syncthreads();
+        for (int i = tid; i < N * w; i += 256) {
+            int r = i / w, c = i - r * w;
+            a.P[(size_t)r * a.ld + N + c0 + c] = T[i];
+            a.P[(size_t)(N + c0 + c) * a.ld + r] = T[i];
+        }
+        __syncthreads();
+    }
+    // write P11 symmetrised ((P + P^T)/2 of msckf.py:334-335; the cross blocks are exact transposes already)
+    for (int i = tid; i < N * N; i += 256) {
+        int r = i / N, c = i - r * N;
+        a.P[(size_t)r * a.ld + c] = (F[r * N + c] + F[c * N + r]) / 2.;
+    }
+}
+
+// ================================================================================================
+// State augmentation (msckf.py:407-423)
+// ================================================================================================
+struct AugArgs { double* P; int n, ld; double R_ic[9]; double sk[9]; };     // sk = skew(R_w_i^T t_c_i)
+
+__global__ __launch_bounds__(256) void augment_kernel(AugArgs a)
+{
+    __shared__ double J[6 * IMU_DIM];
+    __shared__ double C[36];
+    const int tid = threadIdx.x, N = IMU_DIM, n = a.n;
+    for (int i = tid; i < 6 * N; i += 256) J[i] = 0.0;
+    __syncthreads();
+    if (tid < 9) {
+        int r = tid / 3, c = tid % 3;
+        J[r * N + c] = a.R_ic[tid];
+        J[r * N + 15 + c] = r == c ? 1.0 : 0.0;
+        J[(3 + r) * N + c] = a.sk[tid];
+        J[(3 + r) * N + 12 + c] = r == c ? 1.0 : 0.0;
+        J[(3 + r) * N + 18 + c] = r == c ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    // new rows: J P[:21, :n]
+    for (int i = tid; i < 6 * n; i += 256) {
+        int r = i / n, c = i - r * n; double s = 0;
+        for (int k = 0; k < N; ++k) s += J[r * N + k] * a.P[(size_t)k * a.ld + c];
+        a.P[(size_t)(n + r) * a.ld + c] = s;
+    }
+    __syncthreads();
+    // corner: (J P11) J^T, then mirror the new rows into the new columns
+    if (tid < 36) {
+        int r = tid / 6, c = tid % 6; double s = 0;
+        for (int k = 0; k < N; ++k) s += a.P[(size_t)(n + r) * a.ld + k] * J[c * N + k];
+        C[tid] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < 6 * n; i += 256) {
+        int r = i / n, c = i - r * n;
+        a.P[(size_t)c * a.ld + n + r] = a.P[(size_t)(n + r) * a.ld + c];
+    }
+    if (tid < 36) {
+        int r = tid / 6, c = tid % 6;
+        a.P[(size_t)(n + r) * a.ld + n + c] = (C[r * 6 + c] + C[c * 6 + r]) / 2.;
+    }
+}
+
+// ================================================================================================
+// Delete the 6 rows/cols of one camera state (msckf.py:774-786)
+// ================================================================================================
+__global__ __launch_bounds__(256) void remove_cam_kernel(double* P, double* scratch, int n, int ld, int start)
+{
+    // compact into scratch, then copy back (single workgroup; n <= 147)
+    const int tid = threadIdx.x, m = n - 6;
+    for (int i = tid; i < m * m; i += 256) {
+        int r = i / m, c = i - r * m;
+        int sr = r < start ? r : r + 6, sc = c < start ? c : c + 6;
+        scratch[i] = P[(size_t)sr * ld + sc];
+    }
+    __syncthreads();
+    for (int i = tid; i < m * m; i += 256) {
+        int r = i / m, c = i - r * m;
+        P[(size_t)r * ld + c] = scratch[i];
+    }
+}
+
+// ================================================================================================
+// Stacked measurement update (msckf.py:548-602), one 1024-thread workgroup.
+// ================================================================================================
+struct UpdArgs {
+    double* P; int n, ld;
+    const double* Hsrc; const double* rsrc;      // per-feature blocks produced by feature_kernel
+    const int* blk_row; const int* blk_len; int n_blk;
+    double* W;                                   // [m][ld+1] work copy of [H | r]
+    double* T;                                   // [k][ld]
+    double* Kt;                                  // [k][ld]
+    double* Pn;                                  // [n][ld]
+    double* dx;                                  // [n]
+    double obs_noise;
+    int m;                                       // total stacked rows
+};
+
+constexpr int UT = 1024;
+
+__device__ __forceinline__ double block_sum(double v, double* red)
+{
+    const int tid = threadIdx.x;
+    v = wave_sum_f64(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < UT / 64; ++i) s += red[i];
+    return s;
+}
+
+__global__ __launch_bounds__(UT) void update_kernel(UpdArgs a)
+{
+    extern __shared__ double Lp[];               // packed lower triangle of S / its Cholesky factor: k(k+1)/2
+    __shared__ double red[UT / 64];
+    __shared__ double vnorm[2];
+    const int tid = threadIdx.x, n = a.n, m = a.m, ldw = a.ld + 1;
+    // 1. gather the gated feature blocks into W = [H | r]
+    {
+        int row = 0;
+        for (int b = 0; b < a.n_blk; ++b) {
+            const int r0 = a.blk_row[b], len = a.blk_len[b];
+            for (int i = tid; i < len * ldw; i += UT) {
+                int r = i / ldw, c = i - r * ldw;
+                a.W[(size_t)(row + r) * ldw + c] = c < a.ld ? a.Hsrc[(size_t)(r0 + r) * a.ld + c] : a.rsrc[r0 + r];
+            }
+            row += len;
+        }
+    }
+    __syncthreads();
+    // 2. thin QR by Householder when m > n (msckf.py:554-560); afterwards rows 0..k-1 hold [H_thin | r_thin]
+    int k = m;
+    if (m > n) {
+        k = n;
+        for (int j = 0; j < n; ++j) {
+            double part = 0;
+            for (int i = j + tid; i < m; i += UT) { double v = a.W[(size_t)i * ldw + j]; part += v * v; }
+            const double nrm2 = block_sum(part, red);
+            if (tid == 0) {
+                const double ajj = a.W[(size_t)j * ldw + j];
+                const double nrm = sqrt(nrm2);
+                const double alpha = ajj >= 0 ? -nrm : nrm;
+                vnorm[0] = ajj - alpha;                             // v0
+                const double vtv = nrm2 - 2 * alpha * ajj + alpha * alpha;
+                vnorm[1] = vtv > 0 ? 2.0 / vtv : 0.0;               // tau
+                a.W[(size_t)j * ldw + j] = alpha;                   // R_jj
+            }
+            __syncthreads();
+            const double v0 = vnorm[0], tau = vnorm[1];
+            // apply to columns j+1..n-1 and the r column (index ld): one wavefront per column
+            const int wave = tid >> 6, lane = tid & 63, nw = UT / 64;
+            const int ncols = (n - 1 - j) + 1;
+            for (int cj = wave; cj < ncols; cj += nw) {
+                const int c = cj < ncols - 1 ? j + 1 + cj : a.ld;
+                double dot = 0;
+                for (int i = j + 1 + lane; i < m; i += 64) dot += a.W[(size_t)i * ldw + j] * a.W[(size_t)i * ldw + c];
+                dot = wave_sum_f64(dot) + v0 * a.W[(size_t)j * ldw + c];
+                dot *= tau;
+                for (int i = j + 1 + lane; i < m; i += 64) a.W[(size_t)i * ldw + c] -= dot * a.W[(size_t)i * ldw + j];
+                if (lane == 0) a.W[(size_t)j * ldw + c] -= dot * v0;
+            }
+            __syncthreads();
+        }
+        // zero the strictly-lower part of the leading n x n block (the reflector storage)
+        for (int i = tid; i < n * n; i += UT) { int r = i / n, c = i - r * n; if (c < r) a.W[(size_t)r * ldw + c] = 0.0; }
+        __syncthreads();
+    }
+    // 3. T = H_thin P  (k x n)
+    for (int i = tid; i < k * n; i += UT) {
+        int r = i / n, c = i - r * n; double s = 0;
+        for (int q = 0; q < n; ++q) s += a.W[(size_t)r * ldw + q] * a.P[(size_t)q * a.ld + c];
+        a.T[(size_t)r * a.ld + c] = s;
+    }
+    __syncthreads();
+    // 4. S = T H_thin^T + s^2 I, packed lower triangle in LDS
+    for (int i = tid; i < k * (k + 1) / 2; i += UT) {
+        int r = (int)((sqrt(8.0 * i + 1.0) - 1.0) / 2.0);
+        while ((r + 1) * (r + 2) / 2 <= i) ++r;
+        while (r * (r + 1) / 2 > i) --r;
+        int c = i - r * (r + 1) / 2;
+        double s = 0;
+        for (int q = 0; q < n; ++q) s += a.T[(size_t)r * a.ld + q] * a.W[(size_t)c * ldw + q];
+        Lp[i] = s + (r == c ? a.obs_noise : 0.0);
+    }
+    __syncthreads();
+    // 5. Cholesky in LDS
+    for (int j = 0; j < k; ++j) {
+        const int jj = j * (j + 1) / 2 + j;
+        if (tid == 0) Lp[jj] = sqrt(Lp[jj]);
+        __syncthreads();
+        const double d = Lp[jj];
+        for (int i = j + 1 + tid; i < k; i += UT) Lp[i * (i + 1) / 2 + j] /= d;
+        __syncthreads();
+        const int rem = k - j - 1;
+        for (int e = tid; e < rem * rem; e += UT) {
+            const int r = j + 1 + e / rem, c = j + 1 + e % rem;
+            if (c <= r) Lp[r * (r + 1) / 2 + c] -= Lp[r * (r + 1) / 2 + j] * Lp[c * (c + 1) / 2 + j];
+        }
+        __syncthreads();
+    }
+    // 6. K^T = S^-1 T : one thread per right-hand-side column (n columns), forward then backward substitution
+    for (int c = tid; c < n; c += UT) {
+        for (int i = 0; i < k; ++i) {
+            double v = a.T[(size_t)i * a.ld + c];
+            for (int q = 0; q < i; ++q) v -= Lp[i * (i + 1) / 2 + q] * a.Kt[(size_t)q * a.ld + c];
+            a.Kt[(size_t)i * a.ld + c] = v / Lp[i * (i + 1) / 2 + i];
+        }
+        for (int i = k - 1; i >= 0; --i) {
+            double v = a.Kt[(size_t)i * a.ld + c];
+            for (int q = i + 1; q < k; ++q) v -= Lp[q * (q + 1) / 2 + i] * a.Kt[(size_t)q * a.ld + c];
+            a.Kt[(size_t)i * a.ld + c] = v / Lp[i * (i + 1) / 2 + i];
+        }
+    }
+    __syncthreads();
+    // 7. delta_x = K r_thin
+    for (int c = tid; c < n; c += UT) {
+        double s = 0;
+        for (int i = 0; i < k; ++i) s += a.Kt[(size_t)i * a.ld + c] * a.W[(size_t)i * ldw + a.ld];
+        a.dx[c] = s;
+    }
+    // 8. P <- P - K (H_thin P) = P - Kt^T T, then symmetrise
+    for (int i = tid; i < n * n; i += UT) {
+        int r = i / n, c = i - r * n; double s = 0;
+        for (int q = 0; q < k; ++q) s += a.Kt[(size_t)q * a.ld + r] * a.T[(size_t)q * a.ld + c];
+        a.Pn[(size_t)r * a.ld + c] = a.P[(size_t)r * a.ld + c] - s;
+    }
+    __syncthreads();
+    for (int i = tid; i < n * n; i += UT) {
+        int r = i / n, c = i - r * n;
+        a.P[(size_t)r * a.ld + c] = (a.Pn[(size_t)r * a.ld + c] + a.Pn[(size_t)c * a.ld + r]) / 2.;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+// Host side / C ABI
+// ================================================================================================
+struct av_msckf {
+    int device = 0;
+    int max_cam = 0, ld = 0, rows_cap = 0, n = IMU_DIM;
+    double* P = nullptr; double* Pn = nullptr; double* T = nullptr; double* Kt = nullptr; double* W = nullptr;
+    double* Hblk = nullptr; double* rblk = nullptr; double* dx = nullptr; double* chi2 = nullptr; double* scratch = nullptr;
+    std::vector<void*> allocs;
+};
+
+namespace {
+template <typename T>
+int mk_alloc(av_msckf* c, T** p, size_t count)
+{
+    void* q = nullptr;
+    AV_HIP(hipMalloc(&q, count * sizeof(T) + 256));
+    AV_HIP(hipMemset(q, 0, count * sizeof(T) + 256));
+    c->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return AV_OK;
+}
+}  // namespace
+
+AV_EXPORT int av_msckf_create(int max_cam_states, int rows_cap, const double* chi2_table_100, int device, av_msckf** out)
+{
+    if (!out || max_cam_states < 2 || max_cam_states > 40 || rows_cap < 64 || !chi2_table_100) { av_set_error("av_msckf_create: bad arguments"); return AV_E_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { av_set_error("av_msckf_create: no HIP device visible"); return AV_E_NODEVICE; }
+    AV_HIP(hipSetDevice(device));
+    av_msckf* c = new (std::nothrow) av_msckf();
+    if (!c) { av_set_error("out of host memory"); return AV_E_INVALID; }
+    c->device = device; c->max_cam = max_cam_states; c->rows_cap = rows_cap;
+    const int nmax = IMU_DIM + 6 * (max_cam_states + 1);
+    c->ld = (nmax + 7) & ~7;
+    int rc;
+#define A(p, cnt) if ((rc = mk_alloc(c, &(p), (size_t)(cnt)))) { av_msckf_destroy(c); return rc; }
+    A(c->P, (size_t)c->ld * c->ld) A(c->Pn, (size_t)c->ld * c->ld) A(c->T, (size_t)c->ld * c->ld) A(c->Kt, (size_t)c->ld * c->ld)
+    A(c->scratch, (size_t)c->ld * c->ld)
+    A(c->W, (size_t)rows_cap * (c->ld + 1)) A(c->Hblk, (size_t)rows_cap * c->ld) A(c->rblk, rows_cap) A(c->dx, c->ld) A(c->chi2, 100)
+#undef A
+    AV_HIP(hipMemcpy(c->chi2, chi2_table_100, sizeof(double) * 100, hipMemcpyHostToDevice));
+    *out = c;
+    return AV_OK;
+}
+
+AV_EXPORT void av_msckf_destroy(av_msckf* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : c->allocs) (void)hipFree(p);
+    delete c;
+}
+
+AV_EXPORT int av_msckf_ld(const av_msckf* c) { return c ? c->ld : AV_E_INVALID; }
+AV_EXPORT int av_msckf_dim(const av_msckf* c) { return c ? c->n : AV_E_INVALID; }
+
+AV_EXPORT int av_msckf_set_cov(av_msckf* c, const double* P_host, int n, void* stream)
+{
+    if (!c || !P_host || n < IMU_DIM || n > c->ld || (n - IMU_DIM) % 6) { av_set_error("av_msckf_set_cov: bad arguments"); return AV_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    AV_HIP(hipSetDevice(c->device));
+    AV_HIP(hipMemcpy2DAsync(c->P, sizeof(double) * c->ld, P_host, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, st));
+    AV_HIP(hipStreamSynchronize(st));
+    c->n = n;
+    return AV_OK;
+}
+
+AV_EXPORT int av_msckf_get_cov(av_msckf* c, double* P_host, int n, void* stream)
+{
+    if (!c || !P_host || n != c->n) { av_set_error("av_msckf_get_cov: n = %d but the filter has %d states", n, c ? c->n : -1); return AV_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    AV_HIP(hipSetDevice(c->device));
+    AV_HIP(hipMemcpy2DAsync(P_host, sizeof(double) * n, c->P, sizeof(double) * c->ld, sizeof(double) * n, n, hipMemcpyDeviceToHost, st));
+    AV_HIP(hipStreamSynchronize(st));
+    return AV_OK;
+}
+
+AV_EXPORT int av_msckf_propagate(av_msckf* c, double dt, const double gyro[3], const double acc[3], const double q_old[4],
+                                 const double q_new[4], const double q_null[4], const double v_null[3], const double p_null[3],
+                                 const double v_new[3], const double p_new[3], const double gravity[3], const double noise[4],
+                                 void* stream)
+{
+    if (!c || !gyro || !acc || !q_old || !q_new || !q_null || !v_null || !p_null || !v_new || !p_new || !gravity || !noise) {
+        av_set_error("av_msckf_propagate: bad arguments");
+        return AV_E_INVALID;
+    }
+    PropArgs a;
+    a.P = c->P; a.n = c->n; a.ld = c->ld; a.dt = dt;
+    for (int i = 0; i < 3; ++i) { a.gyro[i] = gyro[i]; a.acc[i] = acc[i]; a.v_null[i] = v_null[i]; a.p_null[i] = p_null[i]; a.v_new[i] = v_new[i]; a.p_new[i] = p_new[i]; a.gravity[i] = gravity[i]; }
+    for (int i = 0; i < 4; ++i) { a.q_old[i] = q_old[i]; a.q_new[i] = q_new[i]; a.q_null[i] = q_null[i]; a.noise[i] = noise[i]; }
+    AV_HIP(hipSetDevice(c->device));
+    hipLaunchKernelGGL(propagate_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+AV_EXPORT int av_msckf_augment(av_msckf* c, const double R_imu_cam0[9], const double skew_Rt_t[9], void* stream)
+{
+    if (!c || !R_imu_cam0 || !skew_Rt_t) { av_set_error("av_msckf_augment: bad arguments"); return AV_E_INVALID; }
+    if (c->n + 6 > c->ld) { av_set_error("av_msckf_augment: more than %d camera states", c->max_cam + 1); return AV_E_CAPACITY; }
+    AugArgs a;
+    a.P = c->P; a.n = c->n; a.ld = c->ld;
+    for (int i = 0; i < 9; ++i) { a.R_ic[i] = R_imu_cam0[i]; a.sk[i] = skew_Rt_t[i]; }
+    AV_HIP(hipSetDevice(c->device));
+    hipLaunchKernelGGL(augment_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    AV_LAUNCH_CHECK();
+    c->n += 6;
+    return AV_OK;
+}
+
+AV_EXPORT int av_msckf_remove_cam(av_msckf* c, int cam_index, void* stream)
+{
+    const int ncam = c ? (c->n - IMU_DIM) / 6 : 0;
+    if (!c || cam_index < 0 || cam_index >= ncam) { av_set_error("av_msckf_remove_cam: bad index"); return AV_E_INVALID; }
+    AV_HIP(hipSetDevice(c->device));
+    hipLaunchKernelGGL(remove_cam_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, c->P, c->scratch, c->n, c->ld, IMU_DIM + 6 * cam_index);
+    AV_LAUNCH_CHECK();
+    c->n -= 6;
+    return AV_OK;
+}
+
+AV_EXPORT int av_msckf_triangulate(av_msckf* c, int n_feat, const int32_t* obs_off_dev, const int32_t* obs_cam_dev, const double* obs_z_dev,
+                                   const double* cam_q_dev, const double* cam_p_dev, const double* T_cam0_cam1_rowmajor44,
+                                   const double* opt5, int max_views, double* pos_dev, int32_t* valid_dev, void* stream)
+{
+    if (!c || n_feat < 0 || !obs_off_dev || !obs_cam_dev || !obs_z_dev || !cam_q_dev || !cam_p_dev || !T_cam0_cam1_rowmajor44 || !opt5 || !pos_dev || !valid_dev) {
+        av_set_error("av_msckf_triangulate: bad arguments");
+        return AV_E_INVALID;
+    }
+    if (max_views > 64) { av_set_error("av_msckf_triangulate: %d views per feature exceed one wavefront (64)", max_views); return AV_E_CAPACITY; }
+    if (n_feat == 0) return AV_OK;
+    TriArgs a;
+    a.n_feat = n_feat; a.obs_off = obs_off_dev; a.obs_cam = obs_cam_dev; a.obs_z = obs_z_dev; a.cam_q = cam_q_dev; a.cam_p = cam_p_dev;
+    for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) a.R01[r * 3 + cc] = T_cam0_cam1_rowmajor44[r * 4 + cc]; a.t01[r] = T_cam0_cam1_rowmajor44[r * 4 + 3]; }
+    a.huber = opt5[0]; a.precision = opt5[1]; a.damping = opt5[2]; a.outer_max = (int)opt5[3]; a.inner_max = (int)opt5[4];
+    a.out_pos = pos_dev; a.out_valid = valid_dev;
+    AV_HIP(hipSetDevice(c->device));
+    hipLaunchKernelGGL(triangulate_kernel, dim3((n_feat + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+AV_EXPORT int av_msckf_feature_blocks(av_msckf* c, int n_feat, int n_cam, int max_obs, const int32_t* obs_off_dev, const int32_t* obs_cam_dev,
+                                      const double* obs_z_dev, const double* pos_dev, const int32_t* dof_dev, const int32_t* row_off_dev, int total_rows,
+                                      const double* cam_q_dev, const double* cam_p_dev, const double* cam_qn_dev, const double* cam_pn_dev,
+                                      const double* T_cam0_cam1_rowmajor44, const double gravity[3], double obs_noise,
+                                      double* gamma_dev, int32_t* pass_dev, void* stream)
+{
+    if (!c || n_feat < 0 || !obs_off_dev || !obs_cam_dev || !obs_z_dev || !pos_dev || !dof_dev || !row_off_dev || !cam_q_dev || !cam_p_dev ||
+        !cam_qn_dev || !cam_pn_dev || !T_cam0_cam1_rowmajor44 || !gravity || !gamma_dev || !pass_dev) {
+        av_set_error("av_msckf_feature_blocks: bad arguments");
+        return AV_E_INVALID;
+    }
+    if (IMU_DIM + 6 * n_cam != c->n) { av_set_error("av_msckf_feature_blocks: %d camera states but the covariance has %d states", n_cam, c->n); return AV_E_INVALID; }
+    if (total_rows > c->rows_cap) { av_set_error("av_msckf_feature_blocks: %d stacked rows exceed rows_cap %d", total_rows, c->rows_cap); return AV_E_CAPACITY; }
+    if (max_obs < 2 || max_obs > c->max_cam + 1) { av_set_error("av_msckf_feature_blocks: max_obs %d out of range", max_obs); return AV_E_INVALID; }
+    if (n_feat == 0) return AV_OK;
+    FeatArgs a;
+    a.n_feat = n_feat; a.n_cam = n_cam; a.ld = c->ld;
+    a.obs_off = obs_off_dev; a.obs_cam = obs_cam_dev; a.obs_z = obs_z_dev; a.pos = pos_dev; a.dof = dof_dev; a.row_off = row_off_dev;
+    a.cam_q = cam_q_dev; a.cam_p = cam_p_dev; a.cam_qn = cam_qn_dev; a.cam_pn = cam_pn_dev; a.P = c->P; a.chi2 = c->chi2;
+    for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) a.R01[r * 3 + cc] = T_cam0_cam1_rowmajor44[r * 4 + cc]; a.t01[r] = T_cam0_cam1_rowmajor44[r * 4 + 3]; a.gravity[r] = gravity[r]; }
+    a.obs_noise = obs_noise; a.Hout = c->Hblk; a.rout = c->rblk; a.gamma = gamma_dev; a.pass = pass_dev; a.Mmax = max_obs;
+    const int Mx = max_obs;
+    size_t lds = sizeof(double) * ((size_t)(4 * Mx) * (6 * Mx) + (4 * Mx) * 3 + 4 * Mx + (size_t)(4 * Mx) * (4 * Mx) + 8 * (6 * Mx) + 256) + sizeof(int) * Mx + 16;
+    if (lds > 160 * 1024) { av_set_error("av_msckf_feature_blocks: %d observations per feature need %zu B of LDS", max_obs, lds); return AV_E_CAPACITY; }
+    AV_HIP(hipSetDevice(c->device));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(feature_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(feature_kernel, dim3(n_feat), dim3(256), lds, (hipStream_t)stream, a);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+
+AV_EXPORT int av_msckf_update(av_msckf* c, const int32_t* blk_row_dev, const int32_t* blk_len_dev, int n_blk, int total_rows,
+                              double obs_noise, double* dx_host, void* stream)
+{
+    if (!c || n_blk < 0 || total_rows < 0 || !dx_host || (n_blk > 0 && (!blk_row_dev || !blk_len_dev))) { av_set_error("av_msckf_update: bad arguments"); return AV_E_INVALID; }
+    if (total_rows > c->rows_cap) { av_set_error("av_msckf_update: %d rows exceed rows_cap %d", total_rows, c->rows_cap); return AV_E_CAPACITY; }
+    hipStream_t st = (hipStream_t)stream;
+    if (total_rows == 0) { for (int i = 0; i < c->n; ++i) dx_host[i] = 0.0; return AV_OK; }
+    UpdArgs a;
+    a.P = c->P; a.n = c->n; a.ld = c->ld; a.Hsrc = c->Hblk; a.rsrc = c->rblk; a.blk_row = blk_row_dev; a.blk_len = blk_len_dev; a.n_blk = n_blk;
+    a.W = c->W; a.T = c->T; a.Kt = c->Kt; a.Pn = c->Pn; a.dx = c->dx; a.obs_noise = obs_noise; a.m = total_rows;
+    const int k = total_rows > c->n ? c->n : total_rows;
+    size_t lds = sizeof(double) * ((size_t)k * (k + 1) / 2 + 8);
+    AV_HIP(hipSetDevice(c->device));
+    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(update_kernel, dim3(1), dim3(UT), lds, st, a);
+    AV_LAUNCH_CHECK();
+    AV_HIP(hipMemcpyAsync(dx_host, c->dx, sizeof(double) * c->n, hipMemcpyDeviceToHost, st));
+    AV_HIP(hipStreamSynchronize(st));
+    return AV_OK;
+}

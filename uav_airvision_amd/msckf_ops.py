@@ -1,0 +1,147 @@
+"""Python handle of the MSCKF device context (av_msckf_* C ABI): covariance resident on the GPU, batched
+per-feature kernels, stacked update.  Used by dropin/msckf.py and dropin/feature; numpy in, numpy out."""
+import ctypes as C
+
+import numpy as np
+import torch
+from scipy.stats import chi2
+
+from . import _native as N
+
+
+def _d(a):
+    return (C.c_double * len(a))(*[float(v) for v in a])
+
+
+class FeatureBatch(object):
+    """CSR description of a batch of features on the device."""
+
+    def __init__(self, obs_cam_lists, obs_z_lists, device):
+        dev = torch.device('cuda', device)
+        counts = [len(c) for c in obs_cam_lists]
+        self.n = len(counts)
+        self.max_obs = max(counts) if counts else 0
+        off = np.zeros(self.n + 1, np.int32)
+        off[1:] = np.cumsum(counts)
+        cam = np.concatenate([np.asarray(c, np.int32) for c in obs_cam_lists]) if self.n else np.zeros(0, np.int32)
+        z = np.concatenate([np.asarray(zz, np.float64).reshape(-1, 4) for zz in obs_z_lists]) if self.n else np.zeros((0, 4))
+        self.counts = counts
+        self.off = torch.from_numpy(off).to(dev)
+        self.cam = torch.from_numpy(np.ascontiguousarray(cam)).to(dev)
+        self.z = torch.from_numpy(np.ascontiguousarray(z)).to(dev)
+
+
+class MsckfDevice(object):
+    def __init__(self, max_cam_states=20, rows_cap=8192, device=0):
+        self.device = int(device)
+        self.dev = torch.device('cuda', self.device)
+        table = np.zeros(100)
+        table[1:] = [chi2.ppf(0.05, i) for i in range(1, 100)]          # msckf.py:111-113
+        self.chi2_table = table
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_msckf_create(int(max_cam_states), int(rows_cap), _d(table), self.device, C.byref(self._h)))
+        self.rows_cap = rows_cap
+
+    def close(self):
+        if self._h:
+            N.lib().av_msckf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def dim(self):
+        return N.lib().av_msckf_dim(self._h)
+
+    def _st(self):
+        return N.current_stream()
+
+    def set_cov(self, P):
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_msckf_set_cov(self._h, P.ctypes.data_as(C.c_void_p), P.shape[0], self._st()))
+
+    def get_cov(self):
+        n = self.dim
+        P = np.empty((n, n), np.float64)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_msckf_get_cov(self._h, P.ctypes.data_as(C.c_void_p), n, self._st()))
+        return P
+
+    def propagate(self, dt, gyro, acc, q_old, q_new, q_null, v_null, p_null, v_new, p_new, gravity, noise):
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_msckf_propagate(self._h, float(dt), _d(gyro), _d(acc), _d(q_old), _d(q_new), _d(q_null), _d(v_null),
+                                               _d(p_null), _d(v_new), _d(p_new), _d(gravity), _d(noise), self._st()))
+
+    def augment(self, R_imu_cam0, skew_Rt_t):
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_msckf_augment(self._h, _d(np.asarray(R_imu_cam0).reshape(-1)), _d(np.asarray(skew_Rt_t).reshape(-1)), self._st()))
+
+    def remove_cam(self, idx):
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_msckf_remove_cam(self._h, int(idx), self._st()))
+
+    def _cams(self, cam_q, cam_p):
+        q = torch.from_numpy(np.ascontiguousarray(cam_q, dtype=np.float64).reshape(-1, 4)).to(self.dev)
+        p = torch.from_numpy(np.ascontiguousarray(cam_p, dtype=np.float64).reshape(-1, 3)).to(self.dev)
+        return q, p
+
+    def triangulate(self, batch, cam_q, cam_p, T_cam0_cam1, opt):
+        """-> (positions float64[n,3], valid bool[n])."""
+        if batch.n == 0:
+            return np.zeros((0, 3)), np.zeros(0, bool)
+        q, p = self._cams(cam_q, cam_p)
+        pos = torch.empty((batch.n, 3), dtype=torch.float64, device=self.dev)
+        valid = torch.empty(batch.n, dtype=torch.int32, device=self.dev)
+        opt5 = _d([opt.huber_epsilon, opt.estimation_precision, opt.initial_damping,
+                   opt.outer_loop_max_iteration, opt.inner_loop_max_iteration])
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_msckf_triangulate(self._h, batch.n, N.dptr(batch.off), N.dptr(batch.cam), N.dptr(batch.z), N.dptr(q), N.dptr(p),
+                                                 _d(np.asarray(T_cam0_cam1, dtype=np.float64).reshape(-1)), opt5, 2 * batch.max_obs,
+                                                 N.dptr(pos), N.dptr(valid), self._st()))
+            torch.cuda.synchronize()
+        return pos.cpu().numpy(), valid.cpu().numpy().astype(bool)
+
+    def feature_blocks(self, batch, positions, dofs, cam_q, cam_p, cam_qn, cam_pn, T_cam0_cam1, gravity, obs_noise):
+        """Jacobian + null-space projection + gate for the batch.  -> (row_off int[n], gamma[n], pass bool[n])."""
+        n_cam = len(cam_q)
+        rows = np.array([4 * c - 3 for c in batch.counts], np.int32)
+        row_off = np.zeros(batch.n, np.int32)
+        if batch.n:
+            row_off[1:] = np.cumsum(rows)[:-1]
+        total = int(rows.sum())
+        if batch.n == 0:
+            return row_off, rows, np.zeros(0), np.zeros(0, bool)
+        q, p = self._cams(cam_q, cam_p)
+        qn, pn = self._cams(cam_qn, cam_pn)
+        pos = torch.from_numpy(np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)).to(self.dev)
+        dof = torch.from_numpy(np.ascontiguousarray(dofs, dtype=np.int32)).to(self.dev)
+        ro = torch.from_numpy(row_off).to(self.dev)
+        gamma = torch.empty(batch.n, dtype=torch.float64, device=self.dev)
+        ok = torch.empty(batch.n, dtype=torch.int32, device=self.dev)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_msckf_feature_blocks(self._h, batch.n, n_cam, batch.max_obs, N.dptr(batch.off), N.dptr(batch.cam), N.dptr(batch.z),
+                                                    N.dptr(pos), N.dptr(dof), N.dptr(ro), total, N.dptr(q), N.dptr(p), N.dptr(qn), N.dptr(pn),
+                                                    _d(np.asarray(T_cam0_cam1, dtype=np.float64).reshape(-1)), _d(gravity), float(obs_noise),
+                                                    N.dptr(gamma), N.dptr(ok), self._st()))
+            torch.cuda.synchronize()
+        return row_off, rows, gamma.cpu().numpy(), ok.cpu().numpy().astype(bool)
+
+    def update(self, blk_rows, blk_lens, obs_noise):
+        """Stacked EKF update on the selected blocks; returns delta_x (n doubles)."""
+        n = self.dim
+        dx = np.zeros(n)
+        total = int(np.sum(blk_lens)) if len(blk_lens) else 0
+        if total == 0:
+            return dx
+        br = torch.from_numpy(np.ascontiguousarray(blk_rows, dtype=np.int32)).to(self.dev)
+        bl = torch.from_numpy(np.ascontiguousarray(blk_lens, dtype=np.int32)).to(self.dev)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_msckf_update(self._h, N.dptr(br), N.dptr(bl), len(blk_lens), total, float(obs_noise),
+                                            dx.ctypes.data_as(C.c_void_p), self._st()))
+        return dx
