@@ -102,10 +102,9 @@ def main():
     S, K, Wm = args.streams, args.steps, args.warmup
     F = Wm + K
     # config/seed broadcast from rank 0 over RCCL (config broadcast, no data-path collective)
-    seed_t = torch.tensor([1234 if rank == 0 else 0], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.broadcast(seed_t, 0)
-    base_seed = int(seed_t.item())
+    from uav_airvision_amd import shard
+    run_cfg = shard.broadcast_object({'seed': 1234, 'streams': S, 'steps': K, 'warmup': Wm} if rank == 0 else None)
+    base_seed = int(run_cfg['seed'])
 
     # ---- synthetic data: U rendered streams, replicated to S streams with per-stream pixel noise ----
     U = max(1, min(args.unique, S))
@@ -172,10 +171,7 @@ def main():
         run(k)
     barrier()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed = shard.max_over_ranks(elapsed)
 
     timing = eng.read_timing()
     feats = eng.read_features()                      # raises on any device-side overflow
@@ -184,11 +180,8 @@ def main():
     n_trk = float(np.mean([c['after_tracking'] for c in cnts]))
     n_cand = float(np.mean([c['n_candidates'] for c in cnts]))
     n_pub = float(np.mean([len(f[0]) for f in feats]))
-    stats = torch.tensor([n_t, n_trk, n_cand, n_pub], dtype=torch.float64, device=dev)
-    if world > 1:                                    # trajectory/counter gather is the only end-of-run exchange
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        stats /= world
-    n_t, n_trk, n_cand, n_pub = [float(v) for v in stats.tolist()]
+    # counter reduction is the only end-of-run exchange (no data-path collective)
+    n_t, n_trk, n_cand, n_pub = [float(v) / world for v in shard.sum_over_ranks([n_t, n_trk, n_cand, n_pub])]
 
     fps = world * S * K / elapsed
     b_frame, p_frame = frame_bytes(n_t, n_trk, n_cand)

@@ -1,0 +1,61 @@
+"""The N>1 path on CPU: two gloo ranks shard streams, broadcast the configuration, time with a
+max-over-ranks and gather per-stream trajectories -- the same helpers bench.py uses with RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from uav_airvision_amd import shard
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    cfg = shard.broadcast_object({'seed': 77, 'streams': 5, 'K': np.arange(4.0)} if rank == 0 else None)
+    mine = shard.partition(cfg['streams'], world, rank)
+    # every stream produces a deterministic "trajectory"; streams never talk to each other
+    local = {s: np.full((3 + s, 8), float(cfg['seed'] + s)) for s in mine}
+    t = shard.max_over_ranks(0.1 * (rank + 1))
+    tot = shard.sum_over_ranks([len(mine), sum(mine)])
+    allt = shard.gather_trajectories(local, cfg['streams'], world, rank)
+    q.put((rank, mine, t, tot.tolist(), {k: (v.shape, float(v[0, 0])) for k, v in allt.items()}, cfg['K'].tolist()))
+    dist.destroy_process_group()
+
+
+def test_partition_covers_everything_once():
+    from uav_airvision_amd.shard import partition
+    for n in (0, 1, 5, 8, 64, 67):
+        for w in (1, 2, 3, 8):
+            parts = [partition(n, w, r) for r in range(w)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_two_rank_gloo_sharding():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, m0, t0, tot0, all0, k0), (r1, m1, t1, tot1, all1, k1) = res
+    assert m0 == [0, 1, 2] and m1 == [3, 4]
+    assert abs(t0 - 0.2) < 1e-12 and abs(t1 - 0.2) < 1e-12          # max over ranks
+    assert tot0 == tot1 == [5.0, 10.0]
+    assert all0 == all1 and sorted(all0) == [0, 1, 2, 3, 4]
+    assert all0[4] == ((7, 8), 81.0) and k0 == k1 == [0.0, 1.0, 2.0, 3.0]
