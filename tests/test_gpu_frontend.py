@@ -106,3 +106,16 @@ def test_read_grid_state(cfg):
     assert (g['lifetime'] == 1).all() and (np.diff(g['cell']) >= 0).all()
     assert np.bincount(g['cell']).max() <= cfg.grid_min_feature_num
     eng.close()
+
+
+def test_engine_matches_oracle_fine_grid_config5_shape():
+    """BASELINE configs[4] shape: 10x15 grid (48x51-pixel cells, several cells per FAST tile), up to
+    10 features per cell (1500 per frame)."""
+    from uav_airvision_amd.config import ConfigEuRoC
+    from uav_airvision_amd.synth import SyntheticStream
+    cfg = ConfigEuRoC(grid_row=10, grid_col=15, grid_max_feature_num=10, grid_min_feature_num=4)
+    st = SyntheticStream(cfg, seed=9, n_frames=5, motion_scale=2.0)
+    got = _run_engine(cfg, [st])
+    ref = _run_oracle(cfg, st)
+    assert len(ref[-1][0]) > 1000
+    _compare(ref, got[0], 'n1500')

@@ -10,8 +10,11 @@
 // drops keypoints whose mask pixel is 0 AFTER detection.  Integer-exact.
 //
 // MI355X mapping: one 256-thread workgroup per 64x16 tile; the 72x24 pixel tile and the 66x18
-// score tile live in LDS (2.9 KB), every image byte is read from HBM once (+halo), scores never
-// go to HBM.  Survivors are appended with one atomic each (a few thousand per image), either to a
+// score tile live in LDS (5.3 KB with the candidate list), every image byte is read from HBM once
+// (+halo), scores never go to HBM.  Three phases per tile: (1) a 4-pixel necessary test on every
+// position, survivors compacted into an LDS list with a wave ballot + one LDS atomic per wave,
+// (2) the ~200-op corner score for the compacted candidates only (dense lanes instead of a
+// divergent early-out), (3) 3x3 non-max suppression in LDS.  Survivors are appended with one atomic each (a few thousand per image), either to a
 // flat list or straight into per-grid-cell candidate lists for the feature adder.
 // Bound: HBM read of the image (w*h bytes) -- the score arithmetic is ~200 VALU ops/pixel.
 #include "av_common.h"
@@ -21,6 +24,7 @@ namespace {
 constexpr int TW = 64, TH = 16;
 constexpr int PW = TW + 8, PH = TH + 8;     // pixel tile
 constexpr int SW = TW + 2, SH = TH + 2;     // score tile
+constexpr int MAXLC = 16;                   // grid cells one tile may overlap
 
 struct FastArgs {
     const uint8_t* img;
@@ -65,25 +69,66 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
 {
     __shared__ uint8_t pix[PH * PW];
     __shared__ uint8_t sc[SH * SW];
+    __shared__ uint16_t cand[SH * SW];
+    __shared__ int ncand;
     const int img_i = blockIdx.z;
     const uint8_t* img = a.img + img_i * a.img_stride;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int tid = threadIdx.x;
 
+    if (tid == 0) ncand = 0;
     for (int i = tid; i < PH * PW; i += 256) {
         int r = i / PW, c = i - r * PW;
         int y = min(max(y0 - 4 + r, 0), a.h - 1), x = min(max(x0 - 4 + c, 0), a.w - 1);
         pix[i] = img[(size_t)y * a.img_pitch + x];
     }
     __syncthreads();
-    for (int i = tid; i < SH * SW; i += 256) {
-        int r = i / SW, c = i - r * SW;
-        int y = y0 - 1 + r, x = x0 - 1 + c;
-        int s = 0;
-        if (x >= 3 && x < a.w - 3 && y >= 3 && y < a.h - 3) s = fast_score(&pix[(r + 3) * PW + (c + 3)], a.threshold);
-        sc[i] = (uint8_t)s;
+    // Phase 1: cheap necessary condition on the 4 compass pixels of the ring (any 9-arc contains at
+    // least two of them), survivors compacted into an LDS list so that phase 2 runs dense.
+    const int lane = tid & 63;
+    for (int i0 = 0; i0 < SH * SW; i0 += 256) {
+        const int i = i0 + tid;
+        bool cand_flag = false;
+        if (i < SH * SW) {
+            const int r = i / SW, c = i - r * SW;
+            const int y = y0 - 1 + r, x = x0 - 1 + c;
+            sc[i] = 0;
+            if (x >= 3 && x < a.w - 3 && y >= 3 && y < a.h - 3) {
+                const uint8_t* p = &pix[(r + 3) * PW + (c + 3)];
+                const int v = p[0], t = a.threshold;
+                const int d0 = v - (int)p[3 * PW], d4 = v - (int)p[3], d8 = v - (int)p[-3 * PW], d12 = v - (int)p[-3];
+                const int nb = (d0 > t) + (d4 > t) + (d8 > t) + (d12 > t);
+                const int nd = (d0 < -t) + (d4 < -t) + (d8 < -t) + (d12 < -t);
+                cand_flag = nb >= 2 || nd >= 2;
+            }
+        }
+        const unsigned long long b = __ballot(cand_flag);
+        int base = 0;
+        if (lane == 0 && b) base = atomicAdd(&ncand, __popcll(b));
+        base = __shfl(base, 0, 64);
+        if (cand_flag) cand[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)i;
     }
     __syncthreads();
+    // Phase 2: full corner score only for the candidates
+    const int nc = ncand;
+    for (int k = tid; k < nc; k += 256) {
+        const int i = cand[k];
+        const int r = i / SW, c = i - r * SW;
+        sc[i] = (uint8_t)fast_score(&pix[(r + 3) * PW + (c + 3)], a.threshold);
+    }
+    __syncthreads();
+    // Phase 3: 3x3 non-max suppression + mask; survivors go to an LDS list first so that the tile issues
+    // ONE returning global atomic per output list it touches (a 64x16 tile overlaps <= 4 grid cells)
+    // instead of one per keypoint.
+    __shared__ uint32_t surv_word[256];
+    __shared__ int surv_cell[256];
+    __shared__ int nsurv, cell_base[MAXLC], flat_base;
+    if (tid == 0) nsurv = 0;
+    __syncthreads();
+    // grid cells overlapped by this tile: columns cx0..cx0+ncx-1, rows cy0..cy0+ncy-1 (ncx*ncy <= MAXLC)
+    const int cx0 = a.cell_kp ? x0 / a.gw : 0, cy0 = a.cell_kp ? y0 / a.gh : 0;
+    const int ncx = a.cell_kp ? (min(x0 + TW - 1, a.w - 1) / a.gw - cx0 + 1) : 1;
+    const int ncy = a.cell_kp ? (min(y0 + TH - 1, a.h - 1) / a.gh - cy0 + 1) : 1;
 #pragma unroll
     for (int k = 0; k < (TW * TH) / 256; ++k) {
         int i = tid + 256 * k;
@@ -96,19 +141,44 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
                     s > p[SW - 1] && s > p[SW] && s > p[SW + 1];
         if (keep && a.mask) keep = a.mask[img_i * a.mask_stride + (size_t)y * a.w + x] != 0;
         if (keep) {
-            const uint32_t word = ((uint32_t)s << AV_KP_RASTER_BITS) | (AV_KP_RASTER_MASK - (uint32_t)(y * a.w + x));
-            if (a.n_fast) atomicAdd(&a.n_fast[img_i * a.stat_stride], 1);
-            if (a.kp) {
-                int idx = atomicAdd(&a.count[img_i], 1);
-                if (idx < a.cap) a.kp[(size_t)img_i * a.cap + idx] = word;
-                else if (a.overflow) atomicOr(&a.overflow[img_i * a.stat_stride], 1);
-            }
-            if (a.cell_kp) {
-                int cell = (y / a.gh) * a.grid_col + (x / a.gw);
-                int idx = atomicAdd(&a.cell_count[img_i * a.n_cells + cell], 1);
-                if (idx < a.cell_cap) a.cell_kp[((size_t)img_i * a.n_cells + cell) * a.cell_cap + idx] = word;
-                else if (a.overflow) atomicOr(&a.overflow[img_i * a.stat_stride], 2);
-            }
+            const int slot = atomicAdd(&nsurv, 1);            // LDS atomic; a tile has <= 256 strict maxima
+            surv_word[slot] = ((uint32_t)s << AV_KP_RASTER_BITS) | (AV_KP_RASTER_MASK - (uint32_t)(y * a.w + x));
+            surv_cell[slot] = a.cell_kp ? ((y / a.gh - cy0) * ncx + (x / a.gw - cx0)) : 0;      // tile-local cell index
+        }
+    }
+    __syncthreads();
+    const int ns = nsurv;
+    if (ns == 0) return;
+    if (tid < ncx * ncy) {
+        int cnt = 0;
+        for (int q = 0; q < ns; ++q) cnt += surv_cell[q] == tid;
+        int base = 0;
+        if (a.cell_kp && cnt > 0) {
+            const int cell = (cy0 + tid / ncx) * a.grid_col + (cx0 + tid % ncx);
+            base = atomicAdd(&a.cell_count[img_i * a.n_cells + cell], cnt);
+        }
+        cell_base[tid] = base;
+        if (tid == 0) {
+            if (a.n_fast) atomicAdd(&a.n_fast[img_i * a.stat_stride], ns);
+            flat_base = a.kp ? atomicAdd(&a.count[img_i], ns) : 0;
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < ns; q += 256) {
+        const uint32_t word = surv_word[q];
+        if (a.kp) {
+            const int idx = flat_base + q;
+            if (idx < a.cap) a.kp[(size_t)img_i * a.cap + idx] = word;
+            else if (a.overflow) atomicOr(&a.overflow[img_i * a.stat_stride], 1);
+        }
+        if (a.cell_kp) {
+            const int lc = surv_cell[q];
+            int rank = 0;
+            for (int e = 0; e < q; ++e) rank += surv_cell[e] == lc;
+            const int cell = (cy0 + lc / ncx) * a.grid_col + (cx0 + lc % ncx);
+            const int idx = cell_base[lc] + rank;
+            if (idx < a.cell_cap) a.cell_kp[((size_t)img_i * a.n_cells + cell) * a.cell_cap + idx] = word;
+            else if (a.overflow) atomicOr(&a.overflow[img_i * a.stat_stride], 2);
         }
     }
 }
@@ -124,6 +194,10 @@ int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, const 
     if (n_img <= 0) return AV_OK;
     if ((int64_t)w * h > (int64_t)(AV_KP_RASTER_MASK + 1)) {
         av_set_error("av_fast_detect: image %dx%d exceeds 2^19 pixels", w, h);
+        return AV_E_INVALID;
+    }
+    if (cell_kp && ((TW + gw - 1) / gw + 1) * ((TH + gh - 1) / gh + 1) > MAXLC) {
+        av_set_error("FAST: grid cells of %dx%d pixels are too small (a %dx%d tile may overlap at most %d cells)", gw, gh, TW, TH, MAXLC);
         return AV_E_INVALID;
     }
     FastArgs a;
