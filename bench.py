@@ -27,6 +27,12 @@ sys.path.insert(0, ROOT)
 W_IMG, H_IMG = 752, 480
 LK_BYTES_PER_POINT_PASS = 4 * 2 * 289 + 25          # L=4 levels x (I + J window of 17x17) + point I/O
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/s spec
+# Memory-side traffic of lk_track_kernel per point pass, from rocprofv3 PMC passes of this same command
+# (profiles/r01/pmc_hbm_traffic_s64.json: FETCH_SIZE 112,948 KB and WRITE_SIZE 327 KB per launch of 19,200
+# point passes), corrected as MI355X_MICROARCH.md "HBM" prescribes for gfx950 (FETCH_SIZE x 2; WRITE_SIZE exact).
+# The x2 rule is calibrated for 16-B/lane streams; this kernel stages 32-byte row segments, so read it as an
+# upper bound (uncorrected: 6.0 KB per point pass).
+LK_TRAFFIC_BYTES_PER_POINT_PASS = (2 * 112948.17 + 326.98) * 1024 / 19200
 
 
 def frame_bytes(n_t, n_trk, n_cand):
@@ -40,7 +46,7 @@ def make_config():
     return ConfigEuRoC(grid_row=4, grid_col=5, grid_min_feature_num=3, grid_max_feature_num=15)
 
 
-def cpu_baseline(cfg, budget_s=12.0, max_frames=40):
+def cpu_baseline(cfg, budget_s=10.0, max_frames=400):
     """The CPU oracle (oracle/, scalar C ops + Python glue = a port of the reference's CPU path) on
     ONE stream of the same workload, single thread, bounded sample."""
     from oracle.frontend import OracleFrontend
@@ -77,7 +83,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--streams', type=int, default=64, help='independent stereo streams per GPU')
+    ap.add_argument('--streams', type=int, default=256, help='independent stereo streams per GPU')
     ap.add_argument('--unique', type=int, default=4, help='distinct rendered streams (replicated with per-stream noise)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -207,7 +213,10 @@ def main():
             'roofline': {
                 'bound': 'hbm', 'kernel': 'lk_track_kernel<15>',
                 'achieved': lk_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': lk_gbs / HBM_PEAK_GBS,
-                'traffic': None,
+                'traffic': LK_TRAFFIC_BYTES_PER_POINT_PASS * S * p_frame / 5.0,
+                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r01/pmc_hbm_traffic_s64.json, FETCH x2 per MI355X_MICROARCH.md',
+                'note': 'lk_track_kernel is VALU-issue bound (PMC: VALU busy ~100% at 4 cycles per wave64 instruction), '
+                        'its tiles come from L2/Infinity Cache; the HBM fraction is reported because the path class is byte/integer work',
                 'avg_launch_ms': lk_avg_ms, 'launches': lk_n, 'algorithmic_bytes_per_launch': lk_bytes_per_launch,
             },
             'kernel_ms_per_step': {k: v[0] / K for k, v in timing.items()},
