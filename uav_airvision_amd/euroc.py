@@ -1,0 +1,112 @@
+"""EuRoC MAV dataset reader + deterministic replay.
+
+Counterpart of the reference's `streaming/dataset.py:12-219` (CSV/PNG readers, namedtuple messages,
+start-time offset) and of `streaming/publisher.py:8-53` -- except that the wall-clock-paced publisher
+threads are replaced by the deterministic sequential replay of SURVEY section 3.5 (IMU messages with
+timestamp <= t are delivered before the stereo frame at t), which is what a throughput run needs and
+what makes results reproducible.  PNGs are decoded with Pillow (the reference uses cv2.imread(path, -1),
+dataset.py:110; OpenCV is not a dependency here).
+"""
+import os
+from collections import namedtuple
+
+import numpy as np
+
+imu_msg = namedtuple('imu_msg', ['timestamp', 'angular_velocity', 'linear_acceleration'])
+img_msg = namedtuple('img_msg', ['timestamp', 'image'])
+stereo_msg = namedtuple('stereo_msg', ['timestamp', 'cam0_image', 'cam1_image', 'cam0_msg', 'cam1_msg'])
+gt_msg = namedtuple('gt_msg', ['timestamp', 'p', 'q', 'v', 'bw', 'ba'])
+
+
+def read_image(path):
+    from PIL import Image
+    with Image.open(path) as im:
+        a = np.asarray(im)
+    if a.ndim == 3:
+        a = a[..., 0]
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class EuRoCDataset(object):
+    """`EuRoCDataset(path)` with `.imu`, `.stereo`, `.groundtruth` iterables and
+    `.set_starttime(offset)` (reference: dataset.py:189-219)."""
+
+    def __init__(self, path):
+        self.path = path
+        m = os.path.join(path, 'mav0')
+        self._imu_csv = os.path.join(m, 'imu0', 'data.csv')
+        self._gt_csv = os.path.join(m, 'state_groundtruth_estimate0', 'data.csv')
+        self._cam = [self._list_images(os.path.join(m, 'cam%d' % c, 'data')) for c in (0, 1)]
+        self.timestamps = self._cam[0][1]
+        self._imu = self._load_csv(self._imu_csv, 7)
+        self._gt = self._load_csv(self._gt_csv, 17) if os.path.exists(self._gt_csv) else np.zeros((0, 17))
+        # dataset.py:203: starttime = max(first imu, first stereo)
+        self.starttime0 = max(self._imu[0, 0] if len(self._imu) else -np.inf, self.timestamps[0] if self.timestamps else -np.inf)
+        self.starttime = self.starttime0
+
+    @staticmethod
+    def _list_images(d):
+        names = sorted((n for n in os.listdir(d) if n.endswith('.png')), key=lambda n: float(n[:-4]))
+        return [os.path.join(d, n) for n in names], [float(n[:-4]) * 1e-9 for n in names]
+
+    @staticmethod
+    def _load_csv(path, ncol):
+        rows = []
+        with open(path) as f:
+            next(f)
+            for line in f:
+                v = [float(x) for x in line.strip().split(',')]
+                if len(v) >= ncol:
+                    rows.append(v[:ncol])
+        a = np.array(rows, dtype=np.float64).reshape(-1, ncol)
+        if len(a):
+            a[:, 0] *= 1e-9                              # ns -> s (dataset.py:29,67)
+        return a
+
+    def set_starttime(self, offset):
+        """dataset.py:206-214: everything before starttime0 + offset is skipped."""
+        self.starttime = self.starttime0 + float(offset)
+
+    @property
+    def imu(self):
+        for r in self._imu:
+            if r[0] >= self.starttime:
+                yield imu_msg(r[0], r[1:4].copy(), r[4:7].copy())
+
+    @property
+    def groundtruth(self):
+        for r in self._gt:
+            if r[0] >= self.starttime:
+                yield gt_msg(r[0], r[1:4].copy(), r[4:8].copy(), r[8:11].copy(), r[11:14].copy(), r[14:17].copy())
+
+    @property
+    def stereo(self):
+        (p0, t0), (p1, _t1) = self._cam
+        for k in range(min(len(p0), len(p1))):
+            if t0[k] < self.starttime:
+                continue
+            i0, i1 = read_image(p0[k]), read_image(p1[k])
+            yield stereo_msg(t0[k], i0, i1, img_msg(t0[k], i0), img_msg(t0[k], i1))
+
+    def groundtruth_array(self):
+        """float64[n, 8]: t, p(3), q as stored by EuRoC (w, x, y, z)."""
+        g = self._gt[self._gt[:, 0] >= self.starttime]
+        return g[:, :8].copy()
+
+
+def replay(dataset, imu_sinks, on_stereo, max_frames=None):
+    """Deterministic replay: for each stereo frame at time t deliver every IMU message with
+    timestamp <= t to each sink (order of vio.py:43-44), then call on_stereo(msg)."""
+    it = iter(dataset.imu)
+    pending = next(it, None)
+    n = 0
+    for msg in dataset.stereo:
+        while pending is not None and pending.timestamp <= msg.timestamp:
+            for sink in imu_sinks:
+                sink(pending)
+            pending = next(it, None)
+        on_stereo(msg)
+        n += 1
+        if max_frames is not None and n >= max_frames:
+            break
+    return n
