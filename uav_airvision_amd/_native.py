@@ -80,6 +80,12 @@ SIGNATURES = {
     'av_msckf_feature_blocks': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P,
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, _P, _P, _P]),
     'av_msckf_update': (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, _P, _P]),
+    'av_msckf_batch_create': (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 6 + [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(_P)]),
+    'av_msckf_batch_destroy': (None, [_P]),
+    'av_msckf_batch_push_imu': (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
+    'av_msckf_batch_step': (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P]),
+    'av_msckf_batch_get_cov': (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
+    'av_msckf_batch_sizes': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32 * 3)]),
     'av_frontend_enable_timing': (C.c_int, [_P, C.c_int]),
     'av_frontend_read_timing': (C.c_int, [_P, C.POINTER(C.c_double * 4), C.POINTER(C.c_int32 * 4)]),
 }

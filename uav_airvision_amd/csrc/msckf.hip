@@ -59,8 +59,10 @@ struct TriArgs {
     const int* obs_off;          // [n_feat + 1]
     const int* obs_cam;          // camera-state index of every observation
     const double* obs_z;         // [.][4] = u0 v0 u1 v1
-    const double* cam_q;         // [n_cam][4]
+    const double* cam_q;         // [n_cam][4]   (+ feat_stream[f] * cam_stride entries when batched over streams)
     const double* cam_p;         // [n_cam][3]
+    const int* feat_stream;      // stream of every feature, or NULL (single filter)
+    int cam_stride;              // camera slots per stream
     double R01[9], t01[3];       // cam0 -> cam1 (config.T_cn_cnm1)
     double huber, precision, damping;
     int outer_max, inner_max;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void triangulate_kernel(TriArgs a)
     // pose of this view (camera -> world), feature_position_initializer.py:19-26
     double Rv[9], tv[3], z[2] = {0, 0};
     {
-        const int ci = a.obs_cam[o0 + j];
+        const int ci = a.obs_cam[o0 + j] + (a.feat_stream ? a.feat_stream[f] * a.cam_stride : 0);
         double Rwc[9];
         quat_to_rot(a.cam_q + 4 * ci, Rwc);                 // world -> cam0
         double R0[9];                                       // cam0 -> world = Rwc^T
@@ -254,12 +256,24 @@ struct FeatArgs {
     double* rout;                        // [rows]
     double* gamma; int* pass;            // [n_feat]
     int Mmax;
+    // batching over streams (all NULL / 0 for a single filter)
+    const int* feat_stream;              // stream of every feature
+    const int* stream_ncam;              // camera states per stream
+    const double* stream_gravity;        // [S][3]
+    int cam_stride;                      // camera slots per stream in cam_q / cam_p / cam_qn / cam_pn
+    size_t p_stride, h_stride, r_stride; // elements between streams in P, Hout, rout
 };
 
 __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
 {
     extern __shared__ double sm[];
     const int f = blockIdx.x, tid = threadIdx.x;
+    const int sidx = a.feat_stream ? a.feat_stream[f] : 0;
+    const int cam0 = sidx * a.cam_stride;
+    const double* Pm = a.P + sidx * a.p_stride;
+    double* Hout = a.Hout + sidx * a.h_stride;
+    double* rout = a.rout + sidx * a.r_stride;
+    const double* grav = a.stream_gravity ? a.stream_gravity + 3 * sidx : a.gravity;
     const int o0 = a.obs_off[f], M = a.obs_off[f + 1] - o0;
     const int R4 = 4 * M, C6 = 6 * M, K = R4 - 3;
     const int Mx = a.Mmax;
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
 
     // ---- measurement_jacobian per observation (msckf.py:443-507): thread j < M ---------------------
     if (tid < M) {
-        const int j = tid, ci = a.obs_cam[o0 + j];
+        const int j = tid, ci = cam0 + a.obs_cam[o0 + j];
         double Rw0[9], Rw1[9];
         quat_to_rot(a.cam_q + 4 * ci, Rw0);
 #pragma unroll
@@ -321,7 +335,7 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
         // observability-constrained projection with the null-space states
         double Rn[9], u[6];
         quat_to_rot(a.cam_qn + 4 * ci, Rn);
-        const double* g = a.gravity;
+        const double* g = grav;
 #pragma unroll
         for (int r = 0; r < 3; ++r) u[r] = Rn[r * 3] * g[0] + Rn[r * 3 + 1] * g[1] + Rn[r * 3 + 2] * g[2];
         const double* pn = a.cam_pn + 3 * ci;
@@ -381,18 +395,16 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
     }
     // rows 3..R4-1 of H and r are A^T H_x and A^T r.  Write them out (dense row of width ld).
     const int row0 = a.row_off[f];
-    const int n = IMU_DIM + 6 * a.n_cam;
     for (int i = tid; i < K * a.ld; i += 256) {
         const int rI = i / a.ld, c = i - rI * a.ld;
-        a.Hout[(size_t)(row0 + rI) * a.ld + c] = 0.0;
+        Hout[(size_t)(row0 + rI) * a.ld + c] = 0.0;
     }
     __syncthreads();
     for (int i = tid; i < K * C6; i += 256) {
         const int rI = i / C6, c = i - rI * C6;
-        a.Hout[(size_t)(row0 + rI) * a.ld + IMU_DIM + 6 * cidx[c / 6] + c % 6] = H[(3 + rI) * C6 + c];
+        Hout[(size_t)(row0 + rI) * a.ld + IMU_DIM + 6 * cidx[c / 6] + c % 6] = H[(3 + rI) * C6 + c];
     }
-    for (int i = tid; i < K; i += 256) a.rout[row0 + i] = rr[3 + i];
-    (void)n;
+    for (int i = tid; i < K; i += 256) rout[row0 + i] = rr[3 + i];
 
     // ---- gating test (msckf.py:604-612): S = H' Psub H'^T + s^2 I, gamma = r'^T S^-1 r' -------------
     for (int i0 = 0; i0 < K; i0 += 8) {
@@ -403,7 +415,7 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
             const double* hrow = H + (3 + i0 + ri) * C6;
             const int pd = IMU_DIM + 6 * cidx[d / 6] + d % 6;
             double acc = 0;
-            for (int c = 0; c < C6; ++c) acc += hrow[c] * a.P[(size_t)(IMU_DIM + 6 * cidx[c / 6] + c % 6) * a.ld + pd];
+            for (int c = 0; c < C6; ++c) acc += hrow[c] * Pm[(size_t)(IMU_DIM + 6 * cidx[c / 6] + c % 6) * a.ld + pd];
             Tc[ri * C6 + d] = acc;
         }
         __syncthreads();
@@ -459,7 +471,7 @@ struct PropArgs {
     double noise[4];                 // gyro, gyro_bias, acc, acc_bias (continuous)
 };
 
-__global__ __launch_bounds__(256) void propagate_kernel(PropArgs a)
+__device__ __forceinline__ void propagate_body(const PropArgs& a)
 {
     __shared__ double F[IMU_DIM * IMU_DIM], F2[IMU_DIM * IMU_DIM], Phi[IMU_DIM * IMU_DIM], G[IMU_DIM * 12], T[IMU_DIM * IMU_DIM], Q[IMU_DIM * IMU_DIM];
     __shared__ double Rwi[9], Rnull[9], Rnew[9], u[3], sv[3], w1[3], w2[3];
@@ -583,12 +595,22 @@ __global__ __launch_bounds__(256) void propagate_kernel(PropArgs a)
     }
 }
 
+__global__ __launch_bounds__(256) void propagate_kernel(PropArgs a) { propagate_body(a); }
+// batched: block b applies samples first[b] .. first[b+1]-1 in order (one stream per block)
+__global__ __launch_bounds__(256) void propagate_batch_kernel(const PropArgs* arr, const int* first)
+{
+    for (int i = first[blockIdx.x]; i < first[blockIdx.x + 1]; ++i) {
+        propagate_body(arr[i]);
+        __syncthreads();
+    }
+}
+
 // ================================================================================================
 // State augmentation (msckf.py:407-423)
 // ================================================================================================
 struct AugArgs { double* P; int n, ld; double R_ic[9]; double sk[9]; };     // sk = skew(R_w_i^T t_c_i)
 
-__global__ __launch_bounds__(256) void augment_kernel(AugArgs a)
+__device__ __forceinline__ void augment_body(const AugArgs& a)
 {
     __shared__ double J[6 * IMU_DIM];
     __shared__ double C[36];
@@ -628,10 +650,15 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a)
     }
 }
 
+__global__ __launch_bounds__(256) void augment_kernel(AugArgs a) { augment_body(a); }
+__global__ __launch_bounds__(256) void augment_batch_kernel(const AugArgs* arr) { augment_body(arr[blockIdx.x]); }
+
 // ================================================================================================
 // Delete the 6 rows/cols of one camera state (msckf.py:774-786)
 // ================================================================================================
-__global__ __launch_bounds__(256) void remove_cam_kernel(double* P, double* scratch, int n, int ld, int start)
+struct RemArgs { double* P; double* scratch; int n, ld, start0, start1; };     // start1 < 0: only one removal
+
+__device__ __forceinline__ void remove_cam_body(double* P, double* scratch, int n, int ld, int start)
 {
     // compact into scratch, then copy back (single workgroup; n <= 147)
     const int tid = threadIdx.x, m = n - 6;
@@ -645,6 +672,15 @@ __global__ __launch_bounds__(256) void remove_cam_kernel(double* P, double* scra
         int r = i / m, c = i - r * m;
         P[(size_t)r * ld + c] = scratch[i];
     }
+}
+__global__ __launch_bounds__(256) void remove_cam_kernel(double* P, double* scratch, int n, int ld, int start) { remove_cam_body(P, scratch, n, ld, start); }
+// batched: two removals per stream, the second index already refers to the matrix after the first removal
+__global__ __launch_bounds__(256) void remove_cam_batch_kernel(const RemArgs* arr)
+{
+    const RemArgs a = arr[blockIdx.x];
+    if (a.start0 < 0) return;
+    remove_cam_body(a.P, a.scratch, a.n, a.ld, a.start0);
+    if (a.start1 >= 0) { __syncthreads(); remove_cam_body(a.P, a.scratch, a.n - 6, a.ld, a.start1); }
 }
 
 // ================================================================================================
@@ -678,7 +714,7 @@ __device__ __forceinline__ double block_sum(double v, double* red)
     return s;
 }
 
-__global__ __launch_bounds__(UT) void update_kernel(UpdArgs a)
+__device__ __forceinline__ void update_body(const UpdArgs& a)
 {
     extern __shared__ double Lp[];               // packed lower triangle of S / its Cholesky factor: k(k+1)/2
     __shared__ double red[UT / 64];
@@ -798,6 +834,17 @@ __global__ __launch_bounds__(UT) void update_kernel(UpdArgs a)
         int r = i / n, c = i - r * n;
         a.P[(size_t)r * a.ld + c] = (a.Pn[(size_t)r * a.ld + c] + a.Pn[(size_t)c * a.ld + r]) / 2.;
     }
+}
+__global__ __launch_bounds__(UT) void update_kernel(UpdArgs a) { update_body(a); }
+__global__ __launch_bounds__(UT) void update_batch_kernel(const UpdArgs* arr)
+{
+    if (arr[blockIdx.x].m > 0) update_body(arr[blockIdx.x]);          // block-uniform
+}
+// diag(P)[12..14] of every stream (online_reset, msckf.py:829-835)
+__global__ void pos_var_kernel(const double* P, size_t p_stride, int ld, int S, double* out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * S) { int s = i / 3, k = 12 + i % 3; out[i] = P[s * p_stride + (size_t)k * ld + k]; }
 }
 
 }  // namespace
@@ -937,6 +984,7 @@ AV_EXPORT int av_msckf_triangulate(av_msckf* c, int n_feat, const int32_t* obs_o
     if (n_feat == 0) return AV_OK;
     TriArgs a;
     a.n_feat = n_feat; a.obs_off = obs_off_dev; a.obs_cam = obs_cam_dev; a.obs_z = obs_z_dev; a.cam_q = cam_q_dev; a.cam_p = cam_p_dev;
+    a.feat_stream = nullptr; a.cam_stride = 0;
     for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) a.R01[r * 3 + cc] = T_cam0_cam1_rowmajor44[r * 4 + cc]; a.t01[r] = T_cam0_cam1_rowmajor44[r * 4 + 3]; }
     a.huber = opt5[0]; a.precision = opt5[1]; a.damping = opt5[2]; a.outer_max = (int)opt5[3]; a.inner_max = (int)opt5[4];
     a.out_pos = pos_dev; a.out_valid = valid_dev;
@@ -967,6 +1015,7 @@ AV_EXPORT int av_msckf_feature_blocks(av_msckf* c, int n_feat, int n_cam, int ma
     a.cam_q = cam_q_dev; a.cam_p = cam_p_dev; a.cam_qn = cam_qn_dev; a.cam_pn = cam_pn_dev; a.P = c->P; a.chi2 = c->chi2;
     for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) a.R01[r * 3 + cc] = T_cam0_cam1_rowmajor44[r * 4 + cc]; a.t01[r] = T_cam0_cam1_rowmajor44[r * 4 + 3]; a.gravity[r] = gravity[r]; }
     a.obs_noise = obs_noise; a.Hout = c->Hblk; a.rout = c->rblk; a.gamma = gamma_dev; a.pass = pass_dev; a.Mmax = max_obs;
+    a.feat_stream = nullptr; a.stream_ncam = nullptr; a.stream_gravity = nullptr; a.cam_stride = 0; a.p_stride = a.h_stride = a.r_stride = 0;
     const int Mx = max_obs;
     size_t lds = sizeof(double) * ((size_t)(4 * Mx) * (6 * Mx) + (4 * Mx) * 3 + 4 * Mx + (size_t)(4 * Mx) * (4 * Mx) + 8 * (6 * Mx) + 256) + sizeof(int) * Mx + 16;
     if (lds > 160 * 1024) { av_set_error("av_msckf_feature_blocks: %d observations per feature need %zu B of LDS", max_obs, lds); return AV_E_CAPACITY; }
@@ -997,3 +1046,5 @@ AV_EXPORT int av_msckf_update(av_msckf* c, const int32_t* blk_row_dev, const int
     AV_HIP(hipStreamSynchronize(st));
     return AV_OK;
 }
+
+#include "msckf_batch.inc"

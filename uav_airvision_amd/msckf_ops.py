@@ -145,3 +145,75 @@ class MsckfDevice(object):
             N.check(N.lib().av_msckf_update(self._h, N.dptr(br), N.dptr(bl), len(blk_lens), total, float(obs_noise),
                                             dx.ctypes.data_as(C.c_void_p), self._st()))
         return dx
+
+
+class BatchedMSCKF(object):
+    """S independent filters stepped together (av_msckf_batch_* C ABI): C++ bookkeeping inside the
+    library, one batched launch per numeric phase.  Mirrors MSCKF.imu_callback / feature_callback
+    (reference: src/msckf.py:162-228) for many streams at once."""
+
+    def __init__(self, config, n_streams, device=0, rows_cap=8192):
+        self.config = config
+        self.S = int(n_streams)
+        self.device = int(device)
+        table = np.zeros(100)
+        table[1:] = [chi2.ppf(0.05, i) for i in range(1, 100)]
+        T_cam0_imu = np.linalg.inv(config.T_imu_cam0)
+        rt = np.concatenate([T_cam0_imu[:3, :3].T.reshape(-1), T_cam0_imu[:3, 3]])
+        o = config.optimization_config
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_msckf_batch_create(
+                self.S, int(config.max_cam_state_size), int(rows_cap), _d(table), _d(config.gravity),
+                _d(np.asarray(config.T_cn_cnm1, dtype=np.float64).reshape(-1)), _d(rt),
+                _d([config.gyro_bias_cov, config.velocity_cov, config.acc_bias_cov, config.extrinsic_rotation_cov, config.extrinsic_translation_cov]),
+                _d([config.gyro_noise, config.gyro_bias_noise, config.acc_noise, config.acc_bias_noise]),
+                float(config.observation_noise), float(config.position_std_threshold), _d(config.velocity),
+                _d([o.huber_epsilon, o.estimation_precision, o.initial_damping, o.outer_loop_max_iteration, o.inner_loop_max_iteration, o.translation_threshold]),
+                self.device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            N.lib().av_msckf_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push_imu(self, stream_idx, timestamps, gyro, acc):
+        si = np.ascontiguousarray(stream_idx, dtype=np.int32)
+        ts = np.ascontiguousarray(timestamps, dtype=np.float64)
+        g = np.ascontiguousarray(gyro, dtype=np.float64).reshape(-1, 3)
+        a = np.ascontiguousarray(acc, dtype=np.float64).reshape(-1, 3)
+        N.check(N.lib().av_msckf_batch_push_imu(self._h, si.ctypes.data_as(C.c_void_p), ts.ctypes.data_as(C.c_void_p),
+                                                g.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), len(si)))
+
+    def step(self, ids, uv, n_feat, timestamps):
+        """ids int64[S,cap], uv float64[S,cap,4], n_feat int32[S], timestamps float64[S] (host arrays).
+        Returns float64[S,12]: published, t, p(3), q(4), v(3)."""
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        uv = np.ascontiguousarray(uv, dtype=np.float64)
+        nf = np.ascontiguousarray(n_feat, dtype=np.int32)
+        ts = np.ascontiguousarray(timestamps, dtype=np.float64)
+        cap = ids.shape[1]
+        out = np.zeros((self.S, 12))
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_msckf_batch_step(self._h, ids.ctypes.data_as(C.c_void_p), uv.ctypes.data_as(C.c_void_p),
+                                                nf.ctypes.data_as(C.c_void_p), cap, ts.ctypes.data_as(C.c_void_p),
+                                                out.ctypes.data_as(C.c_void_p), N.current_stream()))
+        return out
+
+    def sizes(self, s):
+        o = (C.c_int32 * 3)()
+        N.check(N.lib().av_msckf_batch_sizes(self._h, int(s), C.byref(o)))
+        return int(o[0]), int(o[1]), int(o[2])
+
+    def get_cov(self, s):
+        n = self.sizes(s)[0]
+        P = np.empty((n, n))
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_msckf_batch_get_cov(self._h, int(s), P.ctypes.data_as(C.c_void_p), n, N.current_stream()))
+        return P
