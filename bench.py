@@ -86,6 +86,7 @@ def main():
     ap.add_argument('--streams', type=int, default=256, help='independent stereo streams per GPU')
     ap.add_argument('--unique', type=int, default=4, help='distinct rendered streams (replicated with per-stream noise)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--with-msckf', action='store_true', help='also run the batched HIP MSCKF on the published features inside the step')
     args = ap.parse_args()
 
     import torch
@@ -140,7 +141,7 @@ def main():
     its = [iter(st.imu) for st in streams]
     pend = [next(it, None) for it in its]
     for k in range(F):
-        idx, ts, gy = [], [], []
+        idx, ts, gy, ac = [], [], [], []
         for u, st in enumerate(streams):
             tf = st.frame_time(k)
             batch = []
@@ -149,17 +150,29 @@ def main():
                 pend[u] = next(its[u], None)
             for s in range(u, S, U):
                 for m in batch:
-                    idx.append(s); ts.append(m.timestamp); gy.append(m.angular_velocity)
-        imu_steps.append((np.array(idx, np.int32), np.array(ts, np.float64), np.array(gy, np.float64).reshape(-1, 3)))
+                    idx.append(s); ts.append(m.timestamp); gy.append(m.angular_velocity); ac.append(m.linear_acceleration)
+        imu_steps.append((np.array(idx, np.int32), np.array(ts, np.float64), np.array(gy, np.float64).reshape(-1, 3),
+                          np.array(ac, np.float64).reshape(-1, 3)))
     frame_ts = [[streams[s % U].frame_time(k) for s in range(S)] for k in range(F)]
     gen_s = time.time() - t_gen
 
     eng = FrontendEngine(cfg, n_streams=S, device=local_rank)
+    flt = None
+    if args.with_msckf:
+        from uav_airvision_amd.msckf_ops import BatchedMSCKF
+        flt = BatchedMSCKF(cfg, S, device=local_rank, rows_cap=4096)
+    msckf_s = [0.0]
 
     def run(k):
-        i, t, gy = imu_steps[k]
+        i, t, gy, ac = imu_steps[k]
         eng.push_imu_batch(i, t, gy)
         eng.step(img0[k], img1[k], frame_ts[k])
+        if flt is not None:
+            t1 = time.perf_counter()
+            flt.push_imu(i, t, gy, ac)
+            ids_h, uv_h, n_h = eng.read_features_raw()     # D2H of ids / normalised coordinates (synchronises)
+            flt.step(ids_h, uv_h, n_h, frame_ts[k])
+            msckf_s[0] += time.perf_counter() - t1
 
     for k in range(Wm):
         run(k)
@@ -172,6 +185,7 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
+    msckf_s[0] = 0.0
     t0 = time.perf_counter()
     for k in range(Wm, F):
         run(k)
@@ -221,6 +235,7 @@ def main():
             },
             'kernel_ms_per_step': {k: v[0] / K for k, v in timing.items()},
             'data_gen_s': gen_s,
+            'msckf_in_step': bool(args.with_msckf), 'msckf_host_ms_per_step': 1e3 * msckf_s[0] / K,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)

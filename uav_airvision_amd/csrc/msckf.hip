@@ -262,12 +262,13 @@ struct FeatArgs {
     const double* stream_gravity;        // [S][3]
     int cam_stride;                      // camera slots per stream in cam_q / cam_p / cam_qn / cam_pn
     size_t p_stride, h_stride, r_stride; // elements between streams in P, Hout, rout
+    const int* feat_list;                // optional: block b processes feature feat_list[b] (launch buckets by track length)
 };
 
 __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
 {
     extern __shared__ double sm[];
-    const int f = blockIdx.x, tid = threadIdx.x;
+    const int f = a.feat_list ? a.feat_list[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
     const int sidx = a.feat_stream ? a.feat_stream[f] : 0;
     const int cam0 = sidx * a.cam_stride;
     const double* Pm = a.P + sidx * a.p_stride;
@@ -690,7 +691,10 @@ struct UpdArgs {
     double* P; int n, ld;
     const double* Hsrc; const double* rsrc;      // per-feature blocks produced by feature_kernel
     const int* blk_row; const int* blk_len; int n_blk;
-    double* W;                                   // [m][ld+1] work copy of [H | r]
+    double* W;                                   // [ld+1][ldt] TRANSPOSED work copy of [H | r] (column c at W + c*ldt)
+    int ldt;                                     // leading dimension of W (>= m)
+    const int* cols; int nc;                     // the non-zero columns of the stacked Jacobian (ascending), device pointer
+    unsigned long long* prof;                    // optional [8] phase timestamps (100 MHz ticks), diagnostic builds/runs only
     double* T;                                   // [k][ld]
     double* Kt;                                  // [k][ld]
     double* Pn;                                  // [n][ld]
@@ -719,75 +723,110 @@ __device__ __forceinline__ void update_body(const UpdArgs& a)
     extern __shared__ double Lp[];               // packed lower triangle of S / its Cholesky factor: k(k+1)/2
     __shared__ double red[UT / 64];
     __shared__ double vnorm[2];
-    const int tid = threadIdx.x, n = a.n, m = a.m, ldw = a.ld + 1;
-    // 1. gather the gated feature blocks into W = [H | r]
+    const int tid = threadIdx.x, n = a.n, m = a.m;
+    // Column compression: the stacked Jacobian is zero outside the 6-wide blocks of the camera states that the
+    // stacked features were observed from (the 21 IMU columns are always zero, msckf.py:535).  Only those nc
+    // columns (a.cols, ascending) are factorised.  Replacing (H, r) by (R, Q^T r) of ANY thin QR of H leaves
+    // delta_x and P+ unchanged (isotropic noise), so compressing to k = min(m, nc) rows is exact; the reference
+    // compresses only when m > n (msckf.py:554) which is the same map in exact arithmetic.
+    auto stamp = [&](int i) { if (a.prof && tid == 0) a.prof[i] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
+    const int nc = a.nc;
+    const size_t ldt = a.ldt;                    // W is stored TRANSPOSED: Wt[q * ldt + i] = H[i][cols[q]]; r lives in row nc.
+    double* Wt = a.W;                            // Column operations of the QR are then contiguous (coalesced) row segments.
+    double* rcol = Wt + (size_t)nc * ldt;
+    // 1. gather the gated feature blocks into Wt
     {
         int row = 0;
         for (int b = 0; b < a.n_blk; ++b) {
             const int r0 = a.blk_row[b], len = a.blk_len[b];
-            for (int i = tid; i < len * ldw; i += UT) {
-                int r = i / ldw, c = i - r * ldw;
-                a.W[(size_t)(row + r) * ldw + c] = c < a.ld ? a.Hsrc[(size_t)(r0 + r) * a.ld + c] : a.rsrc[r0 + r];
+            for (int i = tid; i < len * nc; i += UT) {
+                int r = i / nc, q = i - r * nc;
+                Wt[(size_t)q * ldt + row + r] = a.Hsrc[(size_t)(r0 + r) * a.ld + a.cols[q]];
             }
+            for (int r = tid; r < len; r += UT) rcol[row + r] = a.rsrc[r0 + r];
             row += len;
         }
     }
     __syncthreads();
-    // 2. thin QR by Householder when m > n (msckf.py:554-560); afterwards rows 0..k-1 hold [H_thin | r_thin]
+    stamp(1);
+    // 2. thin QR by Householder when m > nc; afterwards rows 0..k-1 hold [H_thin | r_thin]
     int k = m;
-    if (m > n) {
-        k = n;
-        for (int j = 0; j < n; ++j) {
+    if (m > nc) {
+        k = nc;
+        const int wave = tid >> 6, lane = tid & 63, nw = UT / 64;
+        double* vsh = Lp + (size_t)nc * (nc + 1) / 2 + 8;        // the current reflector, cached in LDS (m doubles)
+        for (int j = 0; j < nc; ++j) {
+            double* vj = Wt + (size_t)j * ldt;                   // column j: reflector tail lives in vj[j+1 .. m)
             double part = 0;
-            for (int i = j + tid; i < m; i += UT) { double v = a.W[(size_t)i * ldw + j]; part += v * v; }
+            for (int i = j + tid; i < m; i += UT) { double v = vj[i]; vsh[i] = v; part += v * v; }
             const double nrm2 = block_sum(part, red);
             if (tid == 0) {
-                const double ajj = a.W[(size_t)j * ldw + j];
+                const double ajj = vj[j];
                 const double nrm = sqrt(nrm2);
                 const double alpha = ajj >= 0 ? -nrm : nrm;
                 vnorm[0] = ajj - alpha;                             // v0
                 const double vtv = nrm2 - 2 * alpha * ajj + alpha * alpha;
                 vnorm[1] = vtv > 0 ? 2.0 / vtv : 0.0;               // tau
-                a.W[(size_t)j * ldw + j] = alpha;                   // R_jj
+                vj[j] = alpha;                                      // R_jj
             }
             __syncthreads();
             const double v0 = vnorm[0], tau = vnorm[1];
-            // apply to columns j+1..n-1 and the r column (index ld): one wavefront per column
-            const int wave = tid >> 6, lane = tid & 63, nw = UT / 64;
-            const int ncols = (n - 1 - j) + 1;
-            for (int cj = wave; cj < ncols; cj += nw) {
-                const int c = cj < ncols - 1 ? j + 1 + cj : a.ld;
-                double dot = 0;
-                for (int i = j + 1 + lane; i < m; i += 64) dot += a.W[(size_t)i * ldw + j] * a.W[(size_t)i * ldw + c];
-                dot = wave_sum_f64(dot) + v0 * a.W[(size_t)j * ldw + c];
-                dot *= tau;
-                for (int i = j + 1 + lane; i < m; i += 64) a.W[(size_t)i * ldw + c] -= dot * a.W[(size_t)i * ldw + j];
-                if (lane == 0) a.W[(size_t)j * ldw + c] -= dot * v0;
+            // apply to columns j+1..nc-1 and the r column.  Each wavefront takes 4 columns at a time with four
+            // independent accumulators, so 4 (dot) resp. 8 (update) L2 requests per lane are in flight instead of a
+            // dependent chain per column; the reflector itself comes from LDS.
+            const int ncols = (nc - 1 - j) + 1;
+            for (int c0 = wave * 4; c0 < ncols; c0 += nw * 4) {
+                double* col[4]; double dot[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cj = min(c0 + u, ncols - 1);
+                    col[u] = cj < ncols - 1 ? Wt + (size_t)(j + 1 + cj) * ldt : rcol;
+                }
+                for (int i = j + 1 + lane; i < m; i += 64) {
+                    const double v = vsh[i];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) dot[u] += v * col[u][i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dot[u] = (wave_sum_f64(dot[u]) + v0 * col[u][j]) * tau;
+                const int nvalid = min(4, ncols - c0);            // duplicates of the last column are not written twice
+                for (int i = j + 1 + lane; i < m; i += 64) {
+                    const double v = vsh[i];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (u < nvalid) col[u][i] -= dot[u] * v;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (lane == u && u < nvalid) col[u][j] -= dot[u] * v0;
             }
             __syncthreads();
         }
-        // zero the strictly-lower part of the leading n x n block (the reflector storage)
-        for (int i = tid; i < n * n; i += UT) { int r = i / n, c = i - r * n; if (c < r) a.W[(size_t)r * ldw + c] = 0.0; }
+        // zero the reflector storage inside the leading nc x nc block (strictly below the diagonal)
+        for (int i = tid; i < nc * nc; i += UT) { int c = i / nc, r = i - c * nc; if (c < r) Wt[(size_t)c * ldt + r] = 0.0; }
         __syncthreads();
     }
-    // 3. T = H_thin P  (k x n)
+    stamp(2);
+    // 3. T = H_thin P  (k x n):  T[r][c] = sum_q Wt[q][r] P[cols[q]][c]
     for (int i = tid; i < k * n; i += UT) {
         int r = i / n, c = i - r * n; double s = 0;
-        for (int q = 0; q < n; ++q) s += a.W[(size_t)r * ldw + q] * a.P[(size_t)q * a.ld + c];
+#pragma unroll 8
+        for (int q = 0; q < nc; ++q) s += Wt[(size_t)q * ldt + r] * a.P[(size_t)a.cols[q] * a.ld + c];
         a.T[(size_t)r * a.ld + c] = s;
     }
     __syncthreads();
-    // 4. S = T H_thin^T + s^2 I, packed lower triangle in LDS
+    // 4. S = T H_thin^T + s^2 I, packed lower triangle in LDS:  S[r][c] = sum_q T[r][cols[q]] Wt[q][c]
     for (int i = tid; i < k * (k + 1) / 2; i += UT) {
         int r = (int)((sqrt(8.0 * i + 1.0) - 1.0) / 2.0);
         while ((r + 1) * (r + 2) / 2 <= i) ++r;
         while (r * (r + 1) / 2 > i) --r;
         int c = i - r * (r + 1) / 2;
         double s = 0;
-        for (int q = 0; q < n; ++q) s += a.T[(size_t)r * a.ld + q] * a.W[(size_t)c * ldw + q];
+#pragma unroll 8
+        for (int q = 0; q < nc; ++q) s += a.T[(size_t)r * a.ld + a.cols[q]] * Wt[(size_t)q * ldt + c];
         Lp[i] = s + (r == c ? a.obs_noise : 0.0);
     }
     __syncthreads();
+    stamp(3);
     // 5. Cholesky in LDS
     for (int j = 0; j < k; ++j) {
         const int jj = j * (j + 1) / 2 + j;
@@ -803,30 +842,43 @@ __device__ __forceinline__ void update_body(const UpdArgs& a)
         }
         __syncthreads();
     }
-    // 6. K^T = S^-1 T : one thread per right-hand-side column (n columns), forward then backward substitution
-    for (int c = tid; c < n; c += UT) {
+    stamp(4);
+    // 6. Y = L^-1 [T | r_thin]: forward substitution only, one thread per right-hand side (n columns of T plus r).
+    //    With S = L L^T:  K r = T^T S^-1 r = Y^T y_r  and  (I - K H) P = P - T^T S^-1 T = P - Y^T Y   (msckf.py:565-602);
+    //    the backward substitution of an explicit K^T = S^-1 T is not needed.  Y overwrites Kt, y_r overwrites rcol.
+    for (int c = tid; c <= n; c += UT) {
+        double* y = c < n ? a.Kt + c : rcol;
+        const double* src = c < n ? a.T + c : rcol;
+        const size_t st_ = c < n ? (size_t)a.ld : 1;
         for (int i = 0; i < k; ++i) {
-            double v = a.T[(size_t)i * a.ld + c];
-            for (int q = 0; q < i; ++q) v -= Lp[i * (i + 1) / 2 + q] * a.Kt[(size_t)q * a.ld + c];
-            a.Kt[(size_t)i * a.ld + c] = v / Lp[i * (i + 1) / 2 + i];
-        }
-        for (int i = k - 1; i >= 0; --i) {
-            double v = a.Kt[(size_t)i * a.ld + c];
-            for (int q = i + 1; q < k; ++q) v -= Lp[q * (q + 1) / 2 + i] * a.Kt[(size_t)q * a.ld + c];
-            a.Kt[(size_t)i * a.ld + c] = v / Lp[i * (i + 1) / 2 + i];
+            double v = src[(size_t)i * st_];
+            const double* Lrow = Lp + (size_t)i * (i + 1) / 2;
+            int q = 0;
+            for (; q + 8 <= i; q += 8) {
+                double yy[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) yy[u] = y[(size_t)(q + u) * st_];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v -= Lrow[q + u] * yy[u];
+            }
+            for (; q < i; ++q) v -= Lrow[q] * y[(size_t)q * st_];
+            y[(size_t)i * st_] = v / Lrow[i];
         }
     }
     __syncthreads();
-    // 7. delta_x = K r_thin
+    stamp(5);
+    // 7. delta_x = Y^T y_r
     for (int c = tid; c < n; c += UT) {
         double s = 0;
-        for (int i = 0; i < k; ++i) s += a.Kt[(size_t)i * a.ld + c] * a.W[(size_t)i * ldw + a.ld];
+#pragma unroll 8
+        for (int i = 0; i < k; ++i) s += a.Kt[(size_t)i * a.ld + c] * rcol[i];
         a.dx[c] = s;
     }
-    // 8. P <- P - K (H_thin P) = P - Kt^T T, then symmetrise
+    // 8. P <- sym(P - Y^T Y)
     for (int i = tid; i < n * n; i += UT) {
         int r = i / n, c = i - r * n; double s = 0;
-        for (int q = 0; q < k; ++q) s += a.Kt[(size_t)q * a.ld + r] * a.T[(size_t)q * a.ld + c];
+#pragma unroll 8
+        for (int q = 0; q < k; ++q) s += a.Kt[(size_t)q * a.ld + r] * a.Kt[(size_t)q * a.ld + c];
         a.Pn[(size_t)r * a.ld + c] = a.P[(size_t)r * a.ld + c] - s;
     }
     __syncthreads();
@@ -834,6 +886,8 @@ __device__ __forceinline__ void update_body(const UpdArgs& a)
         int r = i / n, c = i - r * n;
         a.P[(size_t)r * a.ld + c] = (a.Pn[(size_t)r * a.ld + c] + a.Pn[(size_t)c * a.ld + r]) / 2.;
     }
+    __syncthreads();
+    stamp(6);
 }
 __global__ __launch_bounds__(UT) void update_kernel(UpdArgs a) { update_body(a); }
 __global__ __launch_bounds__(UT) void update_batch_kernel(const UpdArgs* arr)
@@ -856,7 +910,7 @@ struct av_msckf {
     int device = 0;
     int max_cam = 0, ld = 0, rows_cap = 0, n = IMU_DIM;
     double* P = nullptr; double* Pn = nullptr; double* T = nullptr; double* Kt = nullptr; double* W = nullptr;
-    double* Hblk = nullptr; double* rblk = nullptr; double* dx = nullptr; double* chi2 = nullptr; double* scratch = nullptr;
+    double* Hblk = nullptr; double* rblk = nullptr; double* dx = nullptr; double* chi2 = nullptr; double* scratch = nullptr; int* cols_dev = nullptr;
     std::vector<void*> allocs;
 };
 
@@ -889,6 +943,7 @@ AV_EXPORT int av_msckf_create(int max_cam_states, int rows_cap, const double* ch
     A(c->P, (size_t)c->ld * c->ld) A(c->Pn, (size_t)c->ld * c->ld) A(c->T, (size_t)c->ld * c->ld) A(c->Kt, (size_t)c->ld * c->ld)
     A(c->scratch, (size_t)c->ld * c->ld)
     A(c->W, (size_t)rows_cap * (c->ld + 1)) A(c->Hblk, (size_t)rows_cap * c->ld) A(c->rblk, rows_cap) A(c->dx, c->ld) A(c->chi2, 100)
+    A(c->cols_dev, c->ld)
 #undef A
     AV_HIP(hipMemcpy(c->chi2, chi2_table_100, sizeof(double) * 100, hipMemcpyHostToDevice));
     *out = c;
@@ -1016,6 +1071,7 @@ AV_EXPORT int av_msckf_feature_blocks(av_msckf* c, int n_feat, int n_cam, int ma
     for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) a.R01[r * 3 + cc] = T_cam0_cam1_rowmajor44[r * 4 + cc]; a.t01[r] = T_cam0_cam1_rowmajor44[r * 4 + 3]; a.gravity[r] = gravity[r]; }
     a.obs_noise = obs_noise; a.Hout = c->Hblk; a.rout = c->rblk; a.gamma = gamma_dev; a.pass = pass_dev; a.Mmax = max_obs;
     a.feat_stream = nullptr; a.stream_ncam = nullptr; a.stream_gravity = nullptr; a.cam_stride = 0; a.p_stride = a.h_stride = a.r_stride = 0;
+    a.feat_list = nullptr;
     const int Mx = max_obs;
     size_t lds = sizeof(double) * ((size_t)(4 * Mx) * (6 * Mx) + (4 * Mx) * 3 + 4 * Mx + (size_t)(4 * Mx) * (4 * Mx) + 8 * (6 * Mx) + 256) + sizeof(int) * Mx + 16;
     if (lds > 160 * 1024) { av_set_error("av_msckf_feature_blocks: %d observations per feature need %zu B of LDS", max_obs, lds); return AV_E_CAPACITY; }
@@ -1035,10 +1091,18 @@ AV_EXPORT int av_msckf_update(av_msckf* c, const int32_t* blk_row_dev, const int
     if (total_rows == 0) { for (int i = 0; i < c->n; ++i) dx_host[i] = 0.0; return AV_OK; }
     UpdArgs a;
     a.P = c->P; a.n = c->n; a.ld = c->ld; a.Hsrc = c->Hblk; a.rsrc = c->rblk; a.blk_row = blk_row_dev; a.blk_len = blk_len_dev; a.n_blk = n_blk;
-    a.W = c->W; a.T = c->T; a.Kt = c->Kt; a.Pn = c->Pn; a.dx = c->dx; a.obs_noise = obs_noise; a.m = total_rows;
-    const int k = total_rows > c->n ? c->n : total_rows;
-    size_t lds = sizeof(double) * ((size_t)k * (k + 1) / 2 + 8);
+    a.prof = nullptr;
+    a.W = c->W; a.ldt = c->rows_cap; a.T = c->T; a.Kt = c->Kt; a.Pn = c->Pn; a.dx = c->dx; a.obs_noise = obs_noise; a.m = total_rows;
+    // non-zero columns: every camera block (the caller's blocks may involve any of them); the IMU columns are zero
+    std::vector<int> cols;
+    for (int q = IMU_DIM; q < c->n; ++q) cols.push_back(q);
     AV_HIP(hipSetDevice(c->device));
+    AV_HIP(hipMemcpyAsync(c->cols_dev, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice, st));
+    AV_HIP(hipStreamSynchronize(st));
+    a.cols = c->cols_dev; a.nc = (int)cols.size();
+    const int k = total_rows > a.nc ? a.nc : total_rows;
+    size_t lds = sizeof(double) * ((size_t)k * (k + 1) / 2 + 8 + (size_t)total_rows);
+    if (lds > 160 * 1024) { av_set_error("av_msckf_update: %d rows need %zu B of LDS", total_rows, lds); return AV_E_CAPACITY; }
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(update_kernel, dim3(1), dim3(UT), lds, st, a);
     AV_LAUNCH_CHECK();

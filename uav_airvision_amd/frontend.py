@@ -133,6 +133,15 @@ class FrontendEngine(object):
                                                       self._n.ctypes.data_as(C.c_void_p), self.max_features, self._stream()))
         return [(self._ids[s, :self._n[s]].copy(), self._uv[s, :self._n[s]].copy()) for s in range(self.n_streams)]
 
+    def read_features_raw(self):
+        """Synchronises; returns the engine's own host arrays (ids int64[S,cap], uv float64[S,cap,4],
+        n int32[S]) without per-stream copies -- valid until the next read."""
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_frontend_read_features(self._h, self._ids.ctypes.data_as(C.c_void_p),
+                                                      self._uv.ctypes.data_as(C.c_void_p),
+                                                      self._n.ctypes.data_as(C.c_void_p), self.max_features, self._stream()))
+        return self._ids, self._uv, self._n
+
     def read_grid(self, stream=0):
         cap = self.max_features
         ids = np.zeros(cap, np.int64); life = np.zeros(cap, np.int32); cell = np.zeros(cap, np.int32)
