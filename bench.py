@@ -46,26 +46,37 @@ def make_config():
     return ConfigEuRoC(grid_row=4, grid_col=5, grid_min_feature_num=3, grid_max_feature_num=15)
 
 
-def cpu_baseline(cfg, budget_s=10.0, max_frames=400):
-    """The CPU oracle (oracle/, scalar C ops + Python glue = a port of the reference's CPU path) on
-    ONE stream of the same workload, single thread, bounded sample."""
+def cpu_baseline(cfg, with_msckf, budget_s=10.0, max_frames=400):
+    """The CPU oracle (oracle/: scalar C image ops + Python glue + numpy MSCKF = a port of the reference's
+    CPU path) on ONE stream of the same workload, single thread, bounded sample."""
     from oracle.frontend import OracleFrontend
+    from oracle.msckf_np import OracleMSCKF
     from uav_airvision_amd.synth import SyntheticStream
+    try:                                       # "cores": 1 must be true: pin numpy's BLAS to one thread
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
     st = SyntheticStream(cfg, seed=0, n_frames=max_frames)
     frames = []
     fe = OracleFrontend(cfg, cache_pyramids=True)
+    flt = OracleMSCKF(cfg) if with_msckf else None
     it = iter(st.imu)
     pend = next(it, None)
     n = 0
     spent = 0.0
-    warm = 8                                   # let the grid fill up to ~300 features first (not timed)
+    warm = 24 if with_msckf else 8             # grid full (~300 features) and 20 camera states before timing
     for k in range(max_frames):
         m = st.frame(k)
         while pend is not None and pend.timestamp <= m.timestamp:
             fe.imu_callback(pend)
+            if flt is not None:
+                flt.imu_callback(pend)
             pend = next(it, None)
         t0 = time.perf_counter()
         msg = fe.stereo_callback(m)
+        if flt is not None:
+            flt.feature_callback(msg)
         dt = time.perf_counter() - t0
         if k >= warm:
             spent += dt
@@ -74,19 +85,19 @@ def cpu_baseline(cfg, budget_s=10.0, max_frames=400):
             if spent >= budget_s:
                 break
     return dict(value=n / spent, unit='stereo frames/s', cores=1, kind='port',
-                sample='%d frames of 1 synthetic stream after %d warm-up frames, %.1f s, mean %d features/frame'
-                       % (n, warm, spent, int(np.mean(frames))))
+                sample='%d frames of 1 synthetic stream after %d warm-up frames, %.1f s of CPU, mean %d features/frame, %s'
+                       % (n, warm, spent, int(np.mean(frames)), 'front-end + MSCKF' if with_msckf else 'front-end only'))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--streams', type=int, default=256, help='independent stereo streams per GPU')
+    ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--streams', type=int, default=512, help='independent stereo streams per GPU')
     ap.add_argument('--unique', type=int, default=4, help='distinct rendered streams (replicated with per-stream noise)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--with-msckf', action='store_true', help='also run the batched HIP MSCKF on the published features inside the step')
+    ap.add_argument('--frontend-only', action='store_true', help='time only the image front-end (BASELINE configs[1] literally: MSCKF not on the GPU)')
     args = ap.parse_args()
 
     import torch
@@ -107,7 +118,8 @@ def main():
 
     cfg = make_config()
     S, K, Wm = args.streams, args.steps, args.warmup
-    F = Wm + K
+    with_msckf = not args.frontend_only
+    F = Wm + K + (K if with_msckf else 0)      # a second timed loop measures the front-end alone
     # config/seed broadcast from rank 0 over RCCL (config broadcast, no data-path collective)
     from uav_airvision_amd import shard
     run_cfg = shard.broadcast_object({'seed': 1234, 'streams': S, 'steps': K, 'warmup': Wm} if rank == 0 else None)
@@ -158,16 +170,16 @@ def main():
 
     eng = FrontendEngine(cfg, n_streams=S, device=local_rank)
     flt = None
-    if args.with_msckf:
+    if with_msckf:
         from uav_airvision_amd.msckf_ops import BatchedMSCKF
         flt = BatchedMSCKF(cfg, S, device=local_rank, rows_cap=4096)
     msckf_s = [0.0]
 
-    def run(k):
+    def run(k, filt=True):
         i, t, gy, ac = imu_steps[k]
         eng.push_imu_batch(i, t, gy)
         eng.step(img0[k], img1[k], frame_ts[k])
-        if flt is not None:
+        if flt is not None and filt:
             t1 = time.perf_counter()
             flt.push_imu(i, t, gy, ac)
             ids_h, uv_h, n_h = eng.read_features_raw()     # D2H of ids / normalised coordinates (synchronises)
@@ -177,7 +189,7 @@ def main():
     for k in range(Wm):
         run(k)
     eng.read_features()                              # sync + overflow check of the warm-up
-    eng.enable_timing(16 * K + 16)
+    eng.enable_timing(16 * (F - Wm) + 16)
 
     def barrier():
         if world > 1:
@@ -187,13 +199,21 @@ def main():
     barrier()
     msckf_s[0] = 0.0
     t0 = time.perf_counter()
-    for k in range(Wm, F):
+    for k in range(Wm, Wm + K):
         run(k)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed)
-
     timing = eng.read_timing()
+    fe_elapsed = None
+    if with_msckf:                                   # same engine state, next K frames, front-end only
+        barrier()
+        t1 = time.perf_counter()
+        for k in range(Wm + K, F):
+            run(k, filt=False)
+        barrier()
+        fe_elapsed = shard.max_over_ranks(time.perf_counter() - t1)
+
     feats = eng.read_features()                      # raises on any device-side overflow
     cnts = eng.read_all_counters()
     n_t = float(np.mean([c['before_tracking'] for c in cnts]))
@@ -212,13 +232,16 @@ def main():
 
     if rank == 0:
         out = {
-            'metric': 'stereo frames/sec (LK+stereo front-end) at 752x480',
+            'metric': 'stereo frames/sec (LK+stereo+MSCKF-update) at 752x480' if with_msckf else 'stereo frames/sec (LK+stereo front-end) at 752x480',
             'value': fps, 'unit': 'stereo frames/s', 'n_gpus': world, 'steps': K, 'warmup': Wm,
             'ms_per_step': 1e3 * elapsed / K, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'u8/int32 windows, f32 normal equations', 'data': 'synthetic',
             'config': {
-                'workload': 'BASELINE configs[1]: synthetic 752x480 stereo streams, grid 4x5x15 = 300 features/frame, '
-                            'temporal LK + stereo LK fwd/bwd + gates + FAST/grid add/prune/publish on device; MSCKF not in the step',
+                'workload': ('BASELINE configs[1] shape (synthetic 752x480 stereo streams, grid 4x5x15 = 300 features/frame): temporal LK + '
+                             'stereo LK fwd/bwd + gates + FAST/grid add/prune/publish on device, ' +
+                             ('followed in the same step by the batched HIP MSCKF (propagation, augmentation, triangulation, Jacobians + '
+                              'null-space + gate, QR-compressed update, pruning) on the published features'
+                              if with_msckf else 'MSCKF not in the step (configs[1] literally)')),
                 'streams_per_gpu': S, 'unique_rendered_streams': U, 'parallelism': 'stream-sharded x%d' % world,
                 'tracked_features_per_frame': n_t, 'published_features_per_frame': n_pub,
                 'lk_point_passes_per_frame': p_frame, 'algorithmic_bytes_per_frame': b_frame,
@@ -235,10 +258,11 @@ def main():
             },
             'kernel_ms_per_step': {k: v[0] / K for k, v in timing.items()},
             'data_gen_s': gen_s,
-            'msckf_in_step': bool(args.with_msckf), 'msckf_host_ms_per_step': 1e3 * msckf_s[0] / K,
+            'msckf_in_step': with_msckf, 'msckf_wall_ms_per_step': 1e3 * msckf_s[0] / K,
+            'frontend_only_frames_per_s': (world * S * K / fe_elapsed) if fe_elapsed else None,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(cfg)
+            out['cpu_baseline'] = cpu_baseline(cfg, with_msckf)
         print(json.dumps(out))
     eng.close()
     if world > 1:
