@@ -175,16 +175,37 @@ def main():
         flt = BatchedMSCKF(cfg, S, device=local_rank, rows_cap=4096)
     msckf_s = [0.0]
 
-    def run(k, filt=True):
+    filt_stream = torch.cuda.Stream(device=dev) if flt is not None else None
+
+    def run_fe(k):
         i, t, gy, ac = imu_steps[k]
         eng.push_imu_batch(i, t, gy)
         eng.step(img0[k], img1[k], frame_ts[k])
-        if flt is not None and filt:
-            t1 = time.perf_counter()
-            flt.push_imu(i, t, gy, ac)
-            ids_h, uv_h, n_h = eng.read_features_raw()     # D2H of ids / normalised coordinates (synchronises)
+
+    def run_filter(k, ids_h, uv_h, n_h):
+        t1 = time.perf_counter()
+        i, t, gy, ac = imu_steps[k]
+        flt.push_imu(i, t, gy, ac)
+        with torch.cuda.stream(filt_stream):         # the filter's kernels overlap the next frame's front-end kernels
             flt.step(ids_h, uv_h, n_h, frame_ts[k])
-            msckf_s[0] += time.perf_counter() - t1
+        msckf_s[0] += time.perf_counter() - t1
+
+    def run_pipelined(k_begin, k_end):
+        """Full path for frames [k_begin, k_end): the front-end of frame k+1 is enqueued before the (host-blocking)
+        filter step of frame k, so the two overlap on the GPU and with the host bookkeeping."""
+        run_fe(k_begin)
+        for k in range(k_begin, k_end):
+            ids_h, uv_h, n_h = eng.read_features_raw()          # D2H of frame k (synchronises the front-end stream)
+            ids_c, uv_c, n_c = ids_h.copy(), uv_h.copy(), n_h.copy()
+            if k + 1 < k_end:
+                run_fe(k + 1)
+            run_filter(k, ids_c, uv_c, n_c)
+
+    def run(k, filt=True):
+        run_fe(k)
+        if flt is not None and filt:
+            ids_h, uv_h, n_h = eng.read_features_raw()
+            run_filter(k, ids_h, uv_h, n_h)
 
     for k in range(Wm):
         run(k)
@@ -199,8 +220,11 @@ def main():
     barrier()
     msckf_s[0] = 0.0
     t0 = time.perf_counter()
-    for k in range(Wm, Wm + K):
-        run(k)
+    if flt is not None:
+        run_pipelined(Wm, Wm + K)
+    else:
+        for k in range(Wm, Wm + K):
+            run(k)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed)
