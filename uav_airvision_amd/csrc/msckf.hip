@@ -722,7 +722,7 @@ __device__ __forceinline__ void update_body(const UpdArgs& a)
 {
     extern __shared__ double Lp[];               // packed lower triangle of S / its Cholesky factor: k(k+1)/2
     __shared__ double red[UT / 64];
-    __shared__ double vnorm[2];
+    __shared__ double vnorm[3];
     const int tid = threadIdx.x, n = a.n, m = a.m;
     // Column compression: the stacked Jacobian is zero outside the 6-wide blocks of the camera states that the
     // stacked features were observed from (the 21 IMU columns are always zero, msckf.py:535).  Only those nc
@@ -755,14 +755,25 @@ __device__ __forceinline__ void update_body(const UpdArgs& a)
     if (m > nc) {
         k = nc;
         const int wave = tid >> 6, lane = tid & 63, nw = UT / 64;
-        double* vsh = Lp + (size_t)nc * (nc + 1) / 2 + 8;        // the current reflector, cached in LDS (m doubles)
-        for (int j = 0; j < nc; ++j) {
-            double* vj = Wt + (size_t)j * ldt;                   // column j: reflector tail lives in vj[j+1 .. m)
+        // Two LDS buffers hold the current and the next reflector column.  The wavefront that updates column j+1
+        // in step j also accumulates its squared norm and stages it as the next reflector, so a Householder step
+        // costs one pass over the trailing columns and two barriers (no separate norm pass).
+        double* vbuf[2] = {Lp + (size_t)nc * (nc + 1) / 2 + 8, Lp + (size_t)nc * (nc + 1) / 2 + 8 + m};
+        {
+            const double* c0p = Wt;
             double part = 0;
-            for (int i = j + tid; i < m; i += UT) { double v = vj[i]; vsh[i] = v; part += v * v; }
-            const double nrm2 = block_sum(part, red);
+            for (int i = tid; i < m; i += UT) { double v = c0p[i]; vbuf[0][i] = v; part += v * v; }
+            const double n0 = block_sum(part, red);
+            if (tid == 0) vnorm[2] = n0;
+            __syncthreads();
+        }
+        for (int j = 0; j < nc; ++j) {
+            double* vsh = vbuf[j & 1];
+            double* vnext = vbuf[(j + 1) & 1];
+            double* vj = Wt + (size_t)j * ldt;                   // column j in global memory
             if (tid == 0) {
-                const double ajj = vj[j];
+                const double nrm2 = vnorm[2];
+                const double ajj = vsh[j];
                 const double nrm = sqrt(nrm2);
                 const double alpha = ajj >= 0 ? -nrm : nrm;
                 vnorm[0] = ajj - alpha;                             // v0
@@ -772,10 +783,7 @@ __device__ __forceinline__ void update_body(const UpdArgs& a)
             }
             __syncthreads();
             const double v0 = vnorm[0], tau = vnorm[1];
-            // apply to columns j+1..nc-1 and the r column.  Each wavefront takes 4 columns at a time with four
-            // independent accumulators, so 4 (dot) resp. 8 (update) L2 requests per lane are in flight instead of a
-            // dependent chain per column; the reflector itself comes from LDS.
-            const int ncols = (nc - 1 - j) + 1;
+            const int ncols = (nc - 1 - j) + 1;                     // trailing columns j+1..nc-1 plus the r column
             for (int c0 = wave * 4; c0 < ncols; c0 += nw * 4) {
                 double* col[4]; double dot[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -791,13 +799,20 @@ __device__ __forceinline__ void update_body(const UpdArgs& a)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) dot[u] = (wave_sum_f64(dot[u]) + v0 * col[u][j]) * tau;
                 const int nvalid = min(4, ncols - c0);            // duplicates of the last column are not written twice
+                const bool stage_next = (c0 == 0) && (j + 1 < nc);   // col[0] is column j+1: the next reflector
+                double nn = 0;
                 for (int i = j + 1 + lane; i < m; i += 64) {
                     const double v = vsh[i];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) if (u < nvalid) col[u][i] -= dot[u] * v;
+                    for (int u = 0; u < 4; ++u) if (u < nvalid) {
+                        const double nv = col[u][i] - dot[u] * v;
+                        col[u][i] = nv;
+                        if (u == 0 && stage_next) { vnext[i] = nv; nn += nv * nv; }
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) if (lane == u && u < nvalid) col[u][j] -= dot[u] * v0;
+                if (stage_next) { nn = wave_sum_f64(nn); if (lane == 0) vnorm[2] = nn; }
             }
             __syncthreads();
         }
@@ -806,24 +821,59 @@ __device__ __forceinline__ void update_body(const UpdArgs& a)
         __syncthreads();
     }
     stamp(2);
-    // 3. T = H_thin P  (k x n):  T[r][c] = sum_q Wt[q][r] P[cols[q]][c]
-    for (int i = tid; i < k * n; i += UT) {
-        int r = i / n, c = i - r * n; double s = 0;
-#pragma unroll 8
-        for (int q = 0; q < nc; ++q) s += Wt[(size_t)q * ldt + r] * a.P[(size_t)a.cols[q] * a.ld + c];
-        a.T[(size_t)r * a.ld + c] = s;
+    // 3. T = H_thin P  (k x n):  T[r][c] = sum_q Wt[q][r] P[cols[q]][c].  Register-tiled: each thread owns a 4x4
+    //    micro-tile, per q it loads 4 contiguous values of each operand (32 B) and does 16 FMAs.
+    {
+        const int tr = (k + 3) >> 2, tc = (n + 3) >> 2;
+        for (int t = tid; t < tr * tc; t += UT) {
+            const int r0 = (t / tc) * 4, c0 = (t % tc) * 4;
+            double acc[4][4] = {{0}};
+#pragma unroll 4
+            for (int q = 0; q < nc; ++q) {
+                const double* ap = Wt + (size_t)q * ldt + r0;                 // rows r0..r0+3 of column q (ldt >= m >= k; reads past k stay inside the column)
+                const double* bp = a.P + (size_t)a.cols[q] * a.ld + c0;       // ld is padded to a multiple of 8 >= n
+                double av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { av[u] = ap[u]; bv[u] = bp[u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) if (r0 + u < k && c0 + v < n) a.T[(size_t)(r0 + u) * a.ld + c0 + v] = acc[u][v];
+        }
     }
     __syncthreads();
-    // 4. S = T H_thin^T + s^2 I, packed lower triangle in LDS:  S[r][c] = sum_q T[r][cols[q]] Wt[q][c]
-    for (int i = tid; i < k * (k + 1) / 2; i += UT) {
-        int r = (int)((sqrt(8.0 * i + 1.0) - 1.0) / 2.0);
-        while ((r + 1) * (r + 2) / 2 <= i) ++r;
-        while (r * (r + 1) / 2 > i) --r;
-        int c = i - r * (r + 1) / 2;
-        double s = 0;
-#pragma unroll 8
-        for (int q = 0; q < nc; ++q) s += a.T[(size_t)r * a.ld + a.cols[q]] * Wt[(size_t)q * ldt + c];
-        Lp[i] = s + (r == c ? a.obs_noise : 0.0);
+    // 4. S = T H_thin^T + s^2 I, packed lower triangle in LDS:  S[r][c] = sum_q T[r][cols[q]] Wt[q][c]   (4x4 tiles, lower part kept)
+    {
+        const int tk = (k + 3) >> 2;
+        for (int t = tid; t < tk * tk; t += UT) {
+            const int r0 = (t / tk) * 4, c0 = (t % tk) * 4;
+            if (c0 > r0 + 3) continue;                                        // tile entirely above the diagonal
+            double acc[4][4] = {{0}};
+#pragma unroll 4
+            for (int q = 0; q < nc; ++q) {
+                const int cq = a.cols[q];
+                const double* bp = Wt + (size_t)q * ldt + c0;
+                double av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { av[u] = r0 + u < k ? a.T[(size_t)(r0 + u) * a.ld + cq] : 0.0; bv[u] = bp[u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = r0 + u, c = c0 + v;
+                    if (r < k && c <= r) Lp[(size_t)r * (r + 1) / 2 + c] = acc[u][v] + (r == c ? a.obs_noise : 0.0);
+                }
+        }
     }
     __syncthreads();
     stamp(3);
@@ -874,12 +924,29 @@ __device__ __forceinline__ void update_body(const UpdArgs& a)
         for (int i = 0; i < k; ++i) s += a.Kt[(size_t)i * a.ld + c] * rcol[i];
         a.dx[c] = s;
     }
-    // 8. P <- sym(P - Y^T Y)
-    for (int i = tid; i < n * n; i += UT) {
-        int r = i / n, c = i - r * n; double s = 0;
-#pragma unroll 8
-        for (int q = 0; q < k; ++q) s += a.Kt[(size_t)q * a.ld + r] * a.Kt[(size_t)q * a.ld + c];
-        a.Pn[(size_t)r * a.ld + c] = a.P[(size_t)r * a.ld + c] - s;
+    // 8. P <- sym(P - Y^T Y): 4x4 register tiles over the full n x n (Y^T Y is symmetric, so the result already is)
+    {
+        const int tn = (n + 3) >> 2;
+        for (int t = tid; t < tn * tn; t += UT) {
+            const int r0 = (t / tn) * 4, c0 = (t % tn) * 4;
+            double acc[4][4] = {{0}};
+#pragma unroll 4
+            for (int q = 0; q < k; ++q) {
+                const double* yr = a.Kt + (size_t)q * a.ld + r0;
+                const double* yc = a.Kt + (size_t)q * a.ld + c0;
+                double av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { av[u] = yr[u]; bv[u] = yc[u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) if (r0 + u < n && c0 + v < n) a.Pn[(size_t)(r0 + u) * a.ld + c0 + v] = a.P[(size_t)(r0 + u) * a.ld + c0 + v] - acc[u][v];
+        }
     }
     __syncthreads();
     for (int i = tid; i < n * n; i += UT) {
@@ -1101,7 +1168,7 @@ AV_EXPORT int av_msckf_update(av_msckf* c, const int32_t* blk_row_dev, const int
     AV_HIP(hipStreamSynchronize(st));
     a.cols = c->cols_dev; a.nc = (int)cols.size();
     const int k = total_rows > a.nc ? a.nc : total_rows;
-    size_t lds = sizeof(double) * ((size_t)k * (k + 1) / 2 + 8 + (size_t)total_rows);
+    size_t lds = sizeof(double) * ((size_t)k * (k + 1) / 2 + 8 + 2 * (size_t)total_rows);
     if (lds > 160 * 1024) { av_set_error("av_msckf_update: %d rows need %zu B of LDS", total_rows, lds); return AV_E_CAPACITY; }
     AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(update_kernel, dim3(1), dim3(UT), lds, st, a);
