@@ -52,8 +52,8 @@ def _compare(ref, got, tag):
         where = '%s frame %d' % (tag, k)
         if k > 0:
             assert cnt['before_tracking'] == nf['before_tracking'], where
-            assert cnt['after_tracking'] == nf['after_tracking'], where
-            assert cnt['after_matching'] == nf['after_matching'], where
+            assert cnt['after_tracking'] == nf.get('after_tracking', 0), where       # the tracker returns early when nothing was tracked
+            assert cnt['after_matching'] == nf.get('after_matching', 0), where
             assert cnt['n_fast'] == add['n_fast'], where
             assert cnt['n_candidates'] == add['n_candidates'], where
             assert cnt['n_new'] == add['n_new'], where
@@ -119,3 +119,33 @@ def test_engine_matches_oracle_fine_grid_config5_shape():
     ref = _run_oracle(cfg, st)
     assert len(ref[-1][0]) > 1000
     _compare(ref, got[0], 'n1500')
+
+
+def test_engine_blank_and_late_texture_streams(cfg):
+    """Edge cases: a stream of flat images (no corners, empty feature messages, nothing to track) next to a
+    stream whose first frames are flat and then become textured (first-frame initialisation has already
+    happened on an empty image, so features can only enter through the adder)."""
+    from uav_airvision_amd.synth import SyntheticStream, stereo_msg_t, img_msg_t
+
+    class Patched(object):
+        def __init__(self, base, blank_until):
+            self.base, self.blank_until = base, blank_until
+            self.imu, self.n_frames = base.imu, base.n_frames
+
+        def frame_time(self, k):
+            return self.base.frame_time(k)
+
+        def frame(self, k):
+            m = self.base.frame(k)
+            if k < self.blank_until:
+                z0 = np.full_like(m.cam0_image, 97); z1 = np.full_like(m.cam1_image, 97)
+                return stereo_msg_t(m.timestamp, z0, z1, img_msg_t(m.timestamp, z0), img_msg_t(m.timestamp, z1))
+            return m
+    base = SyntheticStream(cfg, seed=12, n_frames=6)
+    streams = [Patched(base, 99), Patched(base, 2)]
+    got = _run_engine(cfg, streams)
+    for i, st in enumerate(streams):
+        ref = _run_oracle(cfg, st)
+        _compare(ref, got[i], 'edge %d' % i)
+    assert all(len(g[0]) == 0 for g in got[0])
+    assert len(got[1][1][0]) == 0 and len(got[1][-1][0]) > 50

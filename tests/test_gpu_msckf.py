@@ -176,3 +176,64 @@ def test_batched_filters_match_reference_golden_and_oracle(cfg):
         assert np.abs(P - Po).max() <= 1e-6 * np.abs(Po).max()
     assert np.abs(bat.get_cov(0) - g['P_149']).max() <= 1e-6 * np.abs(g['P_149']).max()
     bat.close()
+
+
+def test_batched_filter_inactive_stream_and_online_reset():
+    """Stream 1 gets its IMU late (no gravity initialisation for the first frames -> feature_callback returns
+    None, msckf.py:182-183); stream 0 runs with a tiny position_std_threshold so online_reset fires
+    (msckf.py:821-843).  Both must follow the numpy oracle."""
+    from oracle.msckf_np import OracleMSCKF
+    from uav_airvision_amd.config import ConfigEuRoC
+    from uav_airvision_amd.msckf_ops import BatchedMSCKF
+    from uav_airvision_amd.synth import SyntheticFeatureStream
+    cfg = ConfigEuRoC()
+    cfg.position_std_threshold = 0.012
+    n_frames = 60
+    streams = [SyntheticFeatureStream(cfg, seed=31, n_frames=n_frames, n_features=80),
+               SyntheticFeatureStream(cfg, seed=32, n_frames=n_frames, n_features=80)]
+    bat = BatchedMSCKF(cfg, 2)
+    oras = [OracleMSCKF(cfg), OracleMSCKF(cfg)]
+    its = [iter(s.imu) for s in streams]
+    pend = [next(it, None) for it in its]
+    held = []                      # stream 1's IMU is withheld for the first 8 frames
+    resets = 0
+    inactive_frames = 0
+    for k in range(n_frames):
+        msgs = [s.frame(k) for s in streams]
+        si, ts, gy, ac = [], [], [], []
+        for i, m in enumerate(msgs):
+            while pend[i] is not None and pend[i].timestamp <= m.timestamp:
+                if i == 1 and k < 8:
+                    held.append(pend[i])
+                else:
+                    for q in (held if i == 1 else []):
+                        oras[1].imu_callback(q); si.append(1); ts.append(q.timestamp); gy.append(q.angular_velocity); ac.append(q.linear_acceleration)
+                    if i == 1:
+                        held = []
+                    oras[i].imu_callback(pend[i]); si.append(i); ts.append(pend[i].timestamp); gy.append(pend[i].angular_velocity); ac.append(pend[i].linear_acceleration)
+                pend[i] = next(its[i], None)
+        if si:
+            bat.push_imu(si, ts, gy, ac)
+        ids = np.zeros((2, 128), np.int64); uv = np.zeros((2, 128, 4)); nf = np.zeros(2, np.int32)
+        for i, m in enumerate(msgs):
+            nf[i] = len(m.features)
+            for j, f in enumerate(m.features):
+                ids[i, j] = f.id; uv[i, j] = (f.u0, f.v0, f.u1, f.v1)
+        out = bat.step(ids, uv, nf, [m.timestamp for m in msgs])
+        for i, m in enumerate(msgs):
+            ncam_before = len(oras[i].cam_states)
+            r = oras[i].feature_callback(m)
+            assert (r is not None) == bool(out[i, 0]), (k, i)
+            if r is None:
+                inactive_frames += 1
+                continue
+            if len(oras[i].cam_states) == 0 and ncam_before > 0:
+                resets += 1
+            n, ncam, nmap = bat.sizes(i)
+            assert (n, ncam, nmap) == (oras[i].state_cov.shape[0], len(oras[i].cam_states), len(oras[i].map_server)), (k, i)
+            s = oras[i].imu_state
+            assert np.abs(out[i, 2:5] - s.position).max() < 1e-6 and np.abs(out[i, 5:9] - s.orientation).max() < 1e-6, (k, i)
+    assert inactive_frames >= 5 and resets >= 1
+    for i in range(2):
+        assert np.abs(bat.get_cov(i) - oras[i].state_cov).max() <= 1e-6 * max(1e-3, np.abs(oras[i].state_cov).max())
+    bat.close()
