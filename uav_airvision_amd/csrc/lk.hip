@@ -31,6 +31,8 @@
 //     independent of the reduction order and bit-identical to the scalar CPU oracle.
 // Bound: VALU issue + LDS (the staged tiles come from L2: the padded pyramids of a stream are
 // ~560 KB); HBM sees each pyramid once per frame.
+#include <stdlib.h>
+
 #include "av_common.h"
 
 namespace {
@@ -306,6 +308,282 @@ __global__ __launch_bounds__(256) void lk_track_kernel(LKArgs a)
     }
 }
 
+
+// =================================================================================================
+// 16 lanes per point: lane r of a DPP row owns window row r (15 pixels); one wavefront tracks 4 points.
+// Per Newton iteration the pixel work per lane is 15 x (2 perm + 2 dot2 + shift + sub + 2 mad) while the
+// float update of the point (weights, 2x2 solve, stop tests), which is identical for every lane of a point,
+// is now shared by four points per instruction instead of one.  Window sums stay exact: int32 per lane
+// (15 x 8160 x 4080 < 2^31), split into 16-bit halves for the 16-lane DPP butterfly, recombined in fp64.
+// =================================================================================================
+typedef unsigned short av_v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(av_v2u, a) + __builtin_bit_cast(av_v2u, b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(av_v2u, a) - __builtin_bit_cast(av_v2u, b)); }
+__device__ __forceinline__ uint32_t pk_mul(uint32_t a, unsigned short k) { av_v2u kk = {k, k}; return __builtin_bit_cast(uint32_t, __builtin_bit_cast(av_v2u, a) * kk); }
+
+// exact sum over the 16 lanes of a DPP row of an int32 that may overflow when summed: 16-bit halves
+__device__ __forceinline__ double row_sum16_exact(int v)
+{
+    const int lo = row_sum16(v & 0xFFFF), hi = row_sum16(v >> 16);
+    return (double)hi * 65536.0 + (double)lo;
+}
+
+template <int WIN>
+__global__ __launch_bounds__(256) void lk_track_g16_kernel(LKArgs a)
+{
+    static_assert(WIN == 15, "lane map is built for the reference's 15x15 window");
+    constexpr int W_BITS = 14;
+    __shared__ uint32_t tile_all[16][TILE_DWORDS];
+    const int g = threadIdx.x >> 4;                 // point slot of this 16-lane group inside the workgroup
+    const int r = threadIdx.x & 15;                 // window row owned by this lane (row 15 only feeds row 14)
+    uint32_t* tile = tile_all[g];
+    const int s = blockIdx.y;
+    const int pidx = blockIdx.x * 16 + g;
+    const int n = min(a.count[s], a.cap);
+    if (pidx >= n) return;                          // uniform per 16-lane group
+
+    const uint8_t* PI = a.pyrI + s * a.stream_stride;
+    const uint8_t* PJ = a.pyrJ + s * a.stream_stride;
+    const size_t pi = (size_t)s * a.cap + pidx;
+    const float prevx0 = a.prev[2 * pi], prevy0 = a.prev[2 * pi + 1];
+    float curx = a.next[2 * pi], cury = a.next[2 * pi + 1];
+    const float halfWin = (WIN - 1) * 0.5f;
+    const bool rowact = r < WIN;
+    bool ok = true;
+    const double FLT_SCALE_D = 1.0 / (1 << 20);
+
+    for (int level = a.g.levels - 1; level >= 0; --level) {
+        const int w = a.g.w[level], h = a.g.h[level], pitch = a.g.pitch[level];
+        const uint8_t* I = PI + a.g.off[level] + AV_PYR_BORDER * pitch + AV_PYR_BORDER;
+        const uint8_t* J = PJ + a.g.off[level] + AV_PYR_BORDER * pitch + AV_PYR_BORDER;
+        const int col_lo = -AV_PYR_BORDER, col_hi = pitch - AV_PYR_BORDER;
+        const float scale = (float)(1. / (1 << level));
+        float pvx = prevx0 * scale, pvy = prevy0 * scale;
+        if (level == a.g.levels - 1) { curx = curx * scale; cury = cury * scale; }
+        else                         { curx = curx * 2.f;   cury = cury * 2.f; }
+        pvx -= halfWin; pvy -= halfWin;
+        const int ipx = (int)floorf(pvx), ipy = (int)floorf(pvy);
+        if (ipx < -WIN || ipx >= w || ipy < -WIN || ipy >= h) {
+            if (level == 0) ok = false;
+            continue;
+        }
+        float fa = pvx - ipx, fb = pvy - ipy;
+        int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+        int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+        int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        uint32_t wtop = pack16(iw00, iw01), wbot = pack16(iw10, iw11);
+
+        // ---- stage the 18 x 24-byte neighbourhood of the I window (rows ipy-1 .., aligned dwords from cs) ---
+        const int cs = (ipx - 1) & ~3, io = (ipx - 1) - cs;
+        wave_lds_sync();
+        {
+            uint32_t sv[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const int idx = r + 16 * k;                 // 18 rows x 6 dwords = 108
+                const int row = idx / 6, dw = idx - row * 6;
+                const int c = cs + 4 * dw;
+                sv[k] = 0;
+                if (idx < 108 && c >= col_lo && c + 4 <= col_hi) sv[k] = *reinterpret_cast<const uint32_t*>(I + __mul24(ipy - 1 + row, pitch) + c);
+            }
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const int idx = r + 16 * k;
+                const int row = idx / 6, dw = idx - row * 6;
+                if (idx < 108) tile[__mul24(row, TPITCH / 4) + dw] = sv[k];
+            }
+        }
+        wave_lds_sync();
+
+        // ---- I patch + Scharr patches of window row r: staged rows r..r+3, bytes io..io+17 of each -------------
+        int iv[WIN], ixv[WIN], iyv[WIN];
+        int a11 = 0, a12 = 0, a22 = 0;
+        {
+            // E[t][k] = (byte 2k | byte 2k+1 << 16), O[t][k] = (byte 2k+1 | byte 2k+2 << 16) of staged row r+t, bytes counted
+            // from staged column io (= window column -1)
+            uint32_t E[4][9], O[4][8];
+            const int rr = rowact ? r : 14;                   // spare lane 15 recomputes row 14 (masked out below)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t* rowp = tile + __mul24(rr + t, TPITCH / 4);
+                uint32_t d[6], B[5];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) d[k] = rowp[k];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) B[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], io);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {                // bytes 2k, 2k+1
+                    const int b0 = 2 * k;
+                    E[t][k] = __builtin_amdgcn_perm(0, B[b0 >> 2], 0x0C000C00u | (uint32_t)(b0 & 3) | ((uint32_t)((b0 & 3) + 1) << 16));
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {                // bytes 2k+1, 2k+2 (may straddle two dwords)
+                    const int b0 = 2 * k + 1;
+                    const uint32_t lo = B[b0 >> 2], hi2 = B[(b0 + 1) >> 2];
+                    const uint32_t s0 = (uint32_t)(b0 & 3), s1 = ((b0 + 1) >> 2) == (b0 >> 2) ? (uint32_t)((b0 + 1) & 3) : 4u + (uint32_t)((b0 + 1) & 3);
+                    O[t][k] = __builtin_amdgcn_perm(hi2, lo, 0x0C000C00u | s0 | (s1 << 16));
+                }
+            }
+            // vertical passes for window rows r (dy = 0: staged t = 1) and r+1 (dy = 1: t = 2)
+            uint32_t t0E[2][9], t0O[2][8], t1E[2][9], t1O[2][8];
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    t0E[dy][k] = pk_add(pk_mul(pk_add(E[dy][k], E[dy + 2][k]), 3), pk_mul(E[dy + 1][k], 10));
+                    t1E[dy][k] = pk_sub(E[dy + 2][k], E[dy][k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    t0O[dy][k] = pk_add(pk_mul(pk_add(O[dy][k], O[dy + 2][k]), 3), pk_mul(O[dy + 1][k], 10));
+                    t1O[dy][k] = pk_sub(O[dy + 2][k], O[dy][k]);
+                }
+            }
+            // derivative pairs for window columns (c, c+1), c = 0..14.  Staged byte index of window column c is c+1.
+            //   gx[c] = t0[c+2] - t0[c]  (staged),  gy[c] = (t1[c+2] + t1[c]) * 3 + t1[c+1] * 10,   staged centre = c+1
+            // pair for even c = 2k : staged bytes (2k+1, 2k+2) = O-aligned:  gx = t0E[k+1]... see below
+            uint32_t gxp[2][WIN], gyp[2][WIN];
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+                for (int c = 0; c < WIN; ++c) {
+                    // centres at staged bytes (c+1, c+2); left neighbours (c, c+1); right neighbours (c+2, c+3)
+                    const int k = c >> 1;
+                    if ((c & 1) == 0) {        // centres (2k+1, 2k+2) = O[k]; left = E[k]; right = E[k+1]
+                        gxp[dy][c] = pk_sub(t0E[dy][k + 1], t0E[dy][k]);
+                        gyp[dy][c] = pk_add(pk_mul(pk_add(t1E[dy][k + 1], t1E[dy][k]), 3), pk_mul(t1O[dy][k], 10));
+                    } else {                   // centres (2k+2, 2k+3) = E[k+1]; left = O[k]; right = O[k+1]
+                        gxp[dy][c] = pk_sub(t0O[dy][k + 1], t0O[dy][k]);
+                        gyp[dy][c] = pk_add(pk_mul(pk_add(t1O[dy][k + 1], t1O[dy][k]), 3), pk_mul(t1E[dy][k + 1], 10));
+                    }
+                }
+            }
+            // the derivative image is zero outside the image (only near the borders: group-uniform fast path)
+            const bool inside = ipx >= 0 && ipx + WIN < w && ipy >= 0 && ipy + WIN < h;
+            if (!inside) {
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    const bool rowin = (unsigned)(ipy + rr + dy) < (unsigned)h;
+#pragma unroll
+                    for (int c = 0; c < WIN; ++c) {
+                        const uint32_t m0 = (rowin && (unsigned)(ipx + c) < (unsigned)w) ? 0xFFFFu : 0u;
+                        const uint32_t m1 = (rowin && (unsigned)(ipx + c + 1) < (unsigned)w) ? 0xFFFF0000u : 0u;
+                        gxp[dy][c] &= (m0 | m1); gyp[dy][c] &= (m0 | m1);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < WIN; ++c) {
+                // image pairs (window column c, c+1) = staged bytes (c+1, c+2) of staged rows t = 1 (row r) and t = 2 (row r+1)
+                const int k = c >> 1;
+                const uint32_t ptop = (c & 1) == 0 ? O[1][k] : E[1][k + 1];
+                const uint32_t pbot = (c & 1) == 0 ? O[2][k] : E[2][k + 1];
+                const int ival = dot2(ptop, wtop, dot2(pbot, wbot, 1 << (W_BITS - 6))) >> (W_BITS - 5);
+                const int ix = dot2(gxp[0][c], wtop, dot2(gxp[1][c], wbot, 1 << (W_BITS - 1))) >> W_BITS;
+                const int iy = dot2(gyp[0][c], wtop, dot2(gyp[1][c], wbot, 1 << (W_BITS - 1))) >> W_BITS;
+                iv[c] = ival;
+                ixv[c] = rowact ? ix : 0;
+                iyv[c] = rowact ? iy : 0;
+                a11 += __mul24(ixv[c], ixv[c]);
+                a12 += __mul24(ixv[c], iyv[c]);
+                a22 += __mul24(iyv[c], iyv[c]);
+            }
+        }
+        const float A11 = (float)(row_sum16_exact(a11) * FLT_SCALE_D);
+        const float A12 = (float)(row_sum16_exact(a12) * FLT_SCALE_D);
+        const float A22 = (float)(row_sum16_exact(a22) * FLT_SCALE_D);
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+        if ((double)minEig < a.min_eig || D < 1.1920928955078125e-7f) {
+            if (level == 0) ok = false;
+            continue;
+        }
+        D = 1.f / D;
+
+        float wx = curx - halfWin, wy = cury - halfWin;
+        float pdx = 0.f, pdy = 0.f;
+        int X0 = 0, Y0 = 0;
+        bool staged = false;
+        for (int j = 0; j < a.max_iter; ++j) {
+            const int inx = (int)floorf(wx), iny = (int)floorf(wy);
+            if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) {
+                if (level == 0) ok = false;
+                break;
+            }
+            int dx0 = inx - X0, dy0 = iny - Y0;
+            if (!staged || (unsigned)dx0 > 15u || (unsigned)dy0 > 15u) {
+                X0 = min(max((inx - 6) & ~3, col_lo), col_hi - TILE);
+                Y0 = min(max(iny - 8, -AV_PYR_BORDER), h + AV_PYR_BORDER - TILE);
+                wave_lds_sync();
+                uint32_t sv[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int idx = r + 16 * k;                // 32 rows x 8 dwords
+                    sv[k] = *reinterpret_cast<const uint32_t*>(J + __mul24(Y0 + (idx >> 3), pitch) + X0 + 4 * (idx & 7));
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int idx = r + 16 * k;
+                    tile[__mul24(idx >> 3, TPITCH / 4) + (idx & 7)] = sv[k];
+                }
+                wave_lds_sync();
+                staged = true;
+                dx0 = inx - X0; dy0 = iny - Y0;
+            }
+            fa = wx - inx; fb = wy - iny;
+            iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+            iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+            iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            wtop = pack16(iw00, iw01); wbot = pack16(iw10, iw11);
+
+            // this lane's J row (dy0 + r): 16 pixels starting at byte dx0 -> 5 aligned dwords -> 4 byte-aligned dwords
+            const int sh = dx0 & 3;
+            const uint32_t* rp = tile + __mul24(dy0 + r, TPITCH / 4) + (dx0 >> 2);
+            uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2], d3 = rp[3], d4 = rp[4];
+            uint32_t T[5], Bt[5];
+            T[0] = __builtin_amdgcn_alignbyte(d1, d0, sh); T[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            T[2] = __builtin_amdgcn_alignbyte(d3, d2, sh); T[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+            T[4] = 0;
+            // the row below comes from the next lane of the DPP row (row_shl:1)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Bt[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T[k], 0x101, 0xF, 0xF, false);
+            Bt[4] = 0;
+            int b1 = 0, b2 = 0;
+#pragma unroll
+            for (int c = 0; c < WIN; ++c) {
+                const int q = c >> 2, o = c & 3;
+                const uint32_t sel = 0x0C000C00u | (uint32_t)o | ((uint32_t)(o + 1) << 16);     // o+1 == 4 selects byte 0 of the next dword
+                const uint32_t tp = __builtin_amdgcn_perm(T[q + 1], T[q], sel);
+                const uint32_t bp = __builtin_amdgcn_perm(Bt[q + 1], Bt[q], sel);
+                const int v = dot2(tp, wtop, dot2(bp, wbot, 1 << (W_BITS - 6)));
+                const int diff = (v >> (W_BITS - 5)) - iv[c];
+                b1 += __mul24(diff, ixv[c]);
+                b2 += __mul24(diff, iyv[c]);
+            }
+            const float fb1 = (float)(row_sum16_exact(b1) * FLT_SCALE_D);
+            const float fb2 = (float)(row_sum16_exact(b2) * FLT_SCALE_D);
+            const float dx = (A12 * fb2 - A22 * fb1) * D;
+            const float dy = (A12 * fb1 - A11 * fb2) * D;
+            wx += dx; wy += dy;
+            curx = wx + halfWin; cury = wy + halfWin;
+            if ((double)dx * dx + (double)dy * dy <= a.eps2) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                curx -= dx * 0.5f; cury -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+    }
+    if (r == 0) {
+        a.next[2 * pi] = curx;
+        a.next[2 * pi + 1] = cury;
+        a.status[pi] = ok ? 1 : 0;
+    }
+}
+
 }  // namespace
 
 int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride, int n_set, const PyrGeom& g,
@@ -323,8 +601,14 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
     a.prev = prev; a.next = next; a.status = status; a.count = count; a.cap = cap;
     a.max_iter = p.max_iter; a.eps2 = p.eps2; a.min_eig = p.min_eig;
     if (launch_pts > cap) launch_pts = cap;
-    dim3 grid((launch_pts + 3) / 4, n_set);
-    hipLaunchKernelGGL(lk_track_kernel<15>, grid, dim3(256), 0, st, a);
+    static const bool use_w64 = getenv("AV_LK_WAVE_PER_POINT") != nullptr;       // A/B switch: the one-wavefront-per-point kernel
+    if (use_w64) {
+        dim3 grid((launch_pts + 3) / 4, n_set);
+        hipLaunchKernelGGL(lk_track_kernel<15>, grid, dim3(256), 0, st, a);
+    } else {
+        dim3 grid((launch_pts + 15) / 16, n_set);
+        hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
+    }
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
