@@ -325,7 +325,14 @@ __device__ __forceinline__ uint32_t pk_mul(uint32_t a, unsigned short k) { av_v2
 // exact sum over the 16 lanes of a DPP row of an int32 that may overflow when summed: 16-bit halves
 __device__ __forceinline__ double row_sum16_exact(int v)
 {
-    const int lo = row_sum16(v & 0xFFFF), hi = row_sum16(v >> 16);
+    // |v| <= 15 * 8160 * 4080 < 2^29: the sum over a quad still fits int32, the sum over 16 lanes does not
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    int lo = v & 0xFFFF, hi = v >> 16;
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, false); // row_half_mirror
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false);
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, false); // row_mirror
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, false);
     return (double)hi * 65536.0 + (double)lo;
 }
 
@@ -401,10 +408,10 @@ __global__ __launch_bounds__(256) void lk_track_g16_kernel(LKArgs a)
         int iv[WIN], ixv[WIN], iyv[WIN];
         int a11 = 0, a12 = 0, a22 = 0;
         {
-            // E[t][k] = (byte 2k | byte 2k+1 << 16), O[t][k] = (byte 2k+1 | byte 2k+2 << 16) of staged row r+t, bytes counted
-            // from staged column io (= window column -1)
-            uint32_t E[4][9], O[4][8];
-            const int rr = rowact ? r : 14;                   // spare lane 15 recomputes row 14 (masked out below)
+            // staged byte index of window column c is c+1.  E[t][k] = (byte 2k | byte 2k+1 << 16) of staged row r+t,
+            // O[t][k] = (byte 2k+1 | byte 2k+2 << 16): window pair (c, c+1) is O[k] for c = 2k and E[k+1] for c = 2k+1.
+            uint32_t E[4][9], O12[2][8];
+            const int rr = rowact ? r : 14;                   // spare lane 15 recomputes row 14 (dropped at the reductions)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const uint32_t* rowp = tile + __mul24(rr + t, TPITCH / 4);
@@ -418,78 +425,67 @@ __global__ __launch_bounds__(256) void lk_track_g16_kernel(LKArgs a)
                     const int b0 = 2 * k;
                     E[t][k] = __builtin_amdgcn_perm(0, B[b0 >> 2], 0x0C000C00u | (uint32_t)(b0 & 3) | ((uint32_t)((b0 & 3) + 1) << 16));
                 }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {                // bytes 2k+1, 2k+2 (may straddle two dwords)
-                    const int b0 = 2 * k + 1;
-                    const uint32_t lo = B[b0 >> 2], hi2 = B[(b0 + 1) >> 2];
-                    const uint32_t s0 = (uint32_t)(b0 & 3), s1 = ((b0 + 1) >> 2) == (b0 >> 2) ? (uint32_t)((b0 + 1) & 3) : 4u + (uint32_t)((b0 + 1) & 3);
-                    O[t][k] = __builtin_amdgcn_perm(hi2, lo, 0x0C000C00u | s0 | (s1 << 16));
-                }
             }
-            // vertical passes for window rows r (dy = 0: staged t = 1) and r+1 (dy = 1: t = 2)
-            uint32_t t0E[2][9], t0O[2][8], t1E[2][9], t1O[2][8];
+            // (hi half of x | lo half of y << 16): the pair one column to the right of x, given y = the next pair
+            auto mid = [](uint32_t x, uint32_t y) -> uint32_t { return __builtin_amdgcn_perm(y, x, 0x05040302u); };
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) O12[t][k] = mid(E[1 + t][k], E[1 + t][k + 1]);
+            // Scharr on the even window columns (pairs c = 2k, 2k+1); the odd-aligned pairs are byte permutes of those:
+            //   gx[c] = t0[s+1] - t0[s-1],  gy[c] = (t1[s+1] + t1[s-1]) * 3 + t1[s] * 10,  s = c+1,
+            //   t0 = (row above + row below) * 3 + row * 10,  t1 = row below - row above
+            uint32_t gxp[2][WIN + 1], gyp[2][WIN + 1];
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy) {
+                uint32_t t0E[9], t1E[9];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
-                    t0E[dy][k] = pk_add(pk_mul(pk_add(E[dy][k], E[dy + 2][k]), 3), pk_mul(E[dy + 1][k], 10));
-                    t1E[dy][k] = pk_sub(E[dy + 2][k], E[dy][k]);
+                    t0E[k] = pk_add(pk_mul(pk_add(E[dy][k], E[dy + 2][k]), 3), pk_mul(E[dy + 1][k], 10));
+                    t1E[k] = pk_sub(E[dy + 2][k], E[dy][k]);
                 }
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    t0O[dy][k] = pk_add(pk_mul(pk_add(O[dy][k], O[dy + 2][k]), 3), pk_mul(O[dy + 1][k], 10));
-                    t1O[dy][k] = pk_sub(O[dy + 2][k], O[dy][k]);
-                }
-            }
-            // derivative pairs for window columns (c, c+1), c = 0..14.  Staged byte index of window column c is c+1.
-            //   gx[c] = t0[c+2] - t0[c]  (staged),  gy[c] = (t1[c+2] + t1[c]) * 3 + t1[c+1] * 10,   staged centre = c+1
-            // pair for even c = 2k : staged bytes (2k+1, 2k+2) = O-aligned:  gx = t0E[k+1]... see below
-            uint32_t gxp[2][WIN], gyp[2][WIN];
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-#pragma unroll
-                for (int c = 0; c < WIN; ++c) {
-                    // centres at staged bytes (c+1, c+2); left neighbours (c, c+1); right neighbours (c+2, c+3)
-                    const int k = c >> 1;
-                    if ((c & 1) == 0) {        // centres (2k+1, 2k+2) = O[k]; left = E[k]; right = E[k+1]
-                        gxp[dy][c] = pk_sub(t0E[dy][k + 1], t0E[dy][k]);
-                        gyp[dy][c] = pk_add(pk_mul(pk_add(t1E[dy][k + 1], t1E[dy][k]), 3), pk_mul(t1O[dy][k], 10));
-                    } else {                   // centres (2k+2, 2k+3) = E[k+1]; left = O[k]; right = O[k+1]
-                        gxp[dy][c] = pk_sub(t0O[dy][k + 1], t0O[dy][k]);
-                        gyp[dy][c] = pk_add(pk_mul(pk_add(t1O[dy][k + 1], t1O[dy][k]), 3), pk_mul(t1E[dy][k + 1], 10));
-                    }
+                for (int k = 0; k < 8; ++k) {                 // window columns (2k, 2k+1): centres O[k], left E[k], right E[k+1]
+                    gxp[dy][2 * k] = pk_sub(t0E[k + 1], t0E[k]);
+                    gyp[dy][2 * k] = pk_add(pk_mul(pk_add(t1E[k + 1], t1E[k]), 3), pk_mul(mid(t1E[k], t1E[k + 1]), 10));
                 }
             }
-            // the derivative image is zero outside the image (only near the borders: group-uniform fast path)
+            // the derivative image is zero outside the image: only windows at the border pay for the masks
             const bool inside = ipx >= 0 && ipx + WIN < w && ipy >= 0 && ipy + WIN < h;
-            if (!inside) {
+            if (__builtin_amdgcn_ballot_w64(!inside) != 0) {
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
                     const bool rowin = (unsigned)(ipy + rr + dy) < (unsigned)h;
 #pragma unroll
-                    for (int c = 0; c < WIN; ++c) {
-                        const uint32_t m0 = (rowin && (unsigned)(ipx + c) < (unsigned)w) ? 0xFFFFu : 0u;
-                        const uint32_t m1 = (rowin && (unsigned)(ipx + c + 1) < (unsigned)w) ? 0xFFFF0000u : 0u;
-                        gxp[dy][c] &= (m0 | m1); gyp[dy][c] &= (m0 | m1);
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t m0 = (rowin && (unsigned)(ipx + 2 * k) < (unsigned)w) ? 0xFFFFu : 0u;
+                        const uint32_t m1 = (rowin && (unsigned)(ipx + 2 * k + 1) < (unsigned)w) ? 0xFFFF0000u : 0u;
+                        gxp[dy][2 * k] &= (m0 | m1); gyp[dy][2 * k] &= (m0 | m1);
                     }
                 }
             }
 #pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    gxp[dy][2 * k + 1] = mid(gxp[dy][2 * k], gxp[dy][2 * k + 2]);
+                    gyp[dy][2 * k + 1] = mid(gyp[dy][2 * k], gyp[dy][2 * k + 2]);
+                }
+#pragma unroll
             for (int c = 0; c < WIN; ++c) {
-                // image pairs (window column c, c+1) = staged bytes (c+1, c+2) of staged rows t = 1 (row r) and t = 2 (row r+1)
                 const int k = c >> 1;
-                const uint32_t ptop = (c & 1) == 0 ? O[1][k] : E[1][k + 1];
-                const uint32_t pbot = (c & 1) == 0 ? O[2][k] : E[2][k + 1];
+                const uint32_t ptop = (c & 1) == 0 ? O12[0][k] : E[1][k + 1];
+                const uint32_t pbot = (c & 1) == 0 ? O12[1][k] : E[2][k + 1];
                 const int ival = dot2(ptop, wtop, dot2(pbot, wbot, 1 << (W_BITS - 6))) >> (W_BITS - 5);
-                const int ix = dot2(gxp[0][c], wtop, dot2(gxp[1][c], wbot, 1 << (W_BITS - 1))) >> W_BITS;
-                const int iy = dot2(gyp[0][c], wtop, dot2(gyp[1][c], wbot, 1 << (W_BITS - 1))) >> W_BITS;
-                iv[c] = ival;
-                ixv[c] = rowact ? ix : 0;
-                iyv[c] = rowact ? iy : 0;
+                ixv[c] = dot2(gxp[0][c], wtop, dot2(gxp[1][c], wbot, 1 << (W_BITS - 1))) >> W_BITS;
+                iyv[c] = dot2(gyp[0][c], wtop, dot2(gyp[1][c], wbot, 1 << (W_BITS - 1))) >> W_BITS;
+                // accumulator seed of the iteration's interpolation: ((dot + R) >> 9) - ival == (dot + R - (ival << 9)) >> 9
+                iv[c] = (1 << (W_BITS - 6)) - (ival << (W_BITS - 5));
                 a11 += __mul24(ixv[c], ixv[c]);
                 a12 += __mul24(ixv[c], iyv[c]);
                 a22 += __mul24(iyv[c], iyv[c]);
             }
+            if (!rowact) { a11 = 0; a12 = 0; a22 = 0; }
         }
         const float A11 = (float)(row_sum16_exact(a11) * FLT_SCALE_D);
         const float A12 = (float)(row_sum16_exact(a12) * FLT_SCALE_D);
@@ -558,11 +554,11 @@ __global__ __launch_bounds__(256) void lk_track_g16_kernel(LKArgs a)
                 const uint32_t sel = 0x0C000C00u | (uint32_t)o | ((uint32_t)(o + 1) << 16);     // o+1 == 4 selects byte 0 of the next dword
                 const uint32_t tp = __builtin_amdgcn_perm(T[q + 1], T[q], sel);
                 const uint32_t bp = __builtin_amdgcn_perm(Bt[q + 1], Bt[q], sel);
-                const int v = dot2(tp, wtop, dot2(bp, wbot, 1 << (W_BITS - 6)));
-                const int diff = (v >> (W_BITS - 5)) - iv[c];
+                const int diff = dot2(tp, wtop, dot2(bp, wbot, iv[c])) >> (W_BITS - 5);
                 b1 += __mul24(diff, ixv[c]);
                 b2 += __mul24(diff, iyv[c]);
             }
+            if (!rowact) { b1 = 0; b2 = 0; }
             const float fb1 = (float)(row_sum16_exact(b1) * FLT_SCALE_D);
             const float fb2 = (float)(row_sum16_exact(b2) * FLT_SCALE_D);
             const float dx = (A12 * fb2 - A22 * fb1) * D;
