@@ -262,13 +262,38 @@ struct FeatArgs {
     const double* stream_gravity;        // [S][3]
     int cam_stride;                      // camera slots per stream in cam_q / cam_p / cam_qn / cam_pn
     size_t p_stride, h_stride, r_stride; // elements between streams in P, Hout, rout
-    const int* feat_list;                // optional: block b processes feature feat_list[b] (launch buckets by track length)
+    const int* feat_list;                // optional: team t processes feature feat_list[t] (launch buckets by track length)
+    int n_list;                          // teams to run in this launch
+    int team_doubles;                    // LDS doubles per team (wavefront teams: four per workgroup)
 };
 
+// dynamic LDS of feature_kernel for tracks of at most Mx observations (layout at the top of the kernel)
+static inline size_t feature_lds_bytes(int Mx)
+{
+    return sizeof(double) * ((size_t)(4 * Mx) * (6 * Mx) + (4 * Mx) * 3 + 4 * Mx + (size_t)(4 * Mx) * (4 * Mx + 1) + 256) + sizeof(int) * Mx + 16;
+}
+
+// TEAM = threads that cooperate on one feature: a whole 256-thread workgroup for long tracks, one wavefront (four
+// features per workgroup, no workgroup barriers) for tracks of at most 4 observations -- the two-camera prune of
+// msckf.py:714-800 produces ~300 two-observation features per stream and frame, which are latency- not work-bound.
+template <int TEAM>
+__device__ __forceinline__ void team_sync()
+{
+    if (TEAM == 256) __syncthreads();
+    else {      // workgroup-scope fences: the zero fill of the output rows must have landed before other lanes overwrite parts of it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+template <int TEAM>
 __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
 {
-    extern __shared__ double sm[];
-    const int f = a.feat_list ? a.feat_list[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
+    extern __shared__ double sm_all[];
+    const int slot = TEAM == 256 ? (int)blockIdx.x : (int)(blockIdx.x * (256 / TEAM) + threadIdx.x / TEAM);
+    if (slot >= a.n_list) return;                         // whole team
+    const int tid = threadIdx.x % TEAM;
+    double* sm = sm_all + (TEAM == 256 ? 0 : (threadIdx.x / TEAM) * a.team_doubles);
+    const int f = a.feat_list ? a.feat_list[slot] : slot;
     const int sidx = a.feat_stream ? a.feat_stream[f] : 0;
     const int cam0 = sidx * a.cam_stride;
     const double* Pm = a.P + sidx * a.p_stride;
@@ -281,14 +306,14 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
     double* H = sm;                              // [4Mx][6Mx]  row-major, stride C6
     double* Hf = H + (4 * Mx) * (6 * Mx);        // [4Mx][3]
     double* rr = Hf + (4 * Mx) * 3;              // [4Mx]
-    double* S = rr + 4 * Mx;                     // [4Mx][4Mx]
-    double* Tc = S + (4 * Mx) * (4 * Mx);        // [8][6Mx]
-    double* red = Tc + 8 * (6 * Mx);             // [256] reduction scratch
+    double* S = rr + 4 * Mx;                     // [4Mx][4Mx+1]  (odd row pitch: row-wise reflector jobs stay off the same banks)
+    double* red = S + (4 * Mx) * (4 * Mx + 1);   // [256] reduction scratch
+    const int SP = R4 + 1;
     int* cidx = reinterpret_cast<int*>(red + 256);   // [Mx] camera index per observation
 
-    for (int i = tid; i < R4 * C6; i += 256) H[i] = 0.0;
-    for (int i = tid; i < M; i += 256) cidx[i] = a.obs_cam[o0 + i];
-    __syncthreads();
+    for (int i = tid; i < R4 * C6; i += TEAM) H[i] = 0.0;
+    for (int i = tid; i < M; i += TEAM) cidx[i] = a.obs_cam[o0 + i];
+    team_sync<TEAM>();
 
     // ---- measurement_jacobian per observation (msckf.py:443-507): thread j < M ---------------------
     if (tid < M) {
@@ -362,99 +387,147 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
             rr[4 * j + r] = zz[r] - zh[r];
         }
     }
-    __syncthreads();
+    team_sync<TEAM>();
+
+    // ---- G = H_x Psub H_x^T (R4 x R4).  Before the projection H_x is block diagonal (one 4x6 block per observation),
+    //      so G is M x M blocks  Hj P[cam j][cam l] Hl^T: one thread per block pair reads its 6x6 block of P once.  The gate
+    //      matrix A^T H_x Psub H_x^T A (msckf.py:604-612 on the projected Jacobian) is then the trailing K x K block of
+    //      Q^T G Q, with Q the product of the three reflectors below applied from both sides.
+    for (int pr = tid; pr < M * M; pr += TEAM) {
+        const int j = pr / M, l = pr - j * M;
+        const double* Pb = Pm + (size_t)(IMU_DIM + 6 * cidx[j]) * a.ld + IMU_DIM + 6 * cidx[l];
+        const double* Hj = H + (4 * j) * C6 + 6 * j;
+        const double* Hl = H + (4 * l) * C6 + 6 * l;
+        double t[4][6] = {{0}};
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double pv[6];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) pv[d] = Pb[(size_t)c * a.ld + d];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double h = Hj[r * C6 + c];
+#pragma unroll
+                for (int d = 0; d < 6; ++d) t[r][d] += h * pv[d];
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            double hl[6];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) hl[d] = Hl[s2 * C6 + d];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double g = 0;
+#pragma unroll
+                for (int d = 0; d < 6; ++d) g += t[r][d] * hl[d];
+                S[(4 * j + r) * SP + 4 * l + s2] = g;
+            }
+        }
+    }
+    team_sync<TEAM>();
 
     // ---- left null space of H_f by 3 Householder reflectors, applied to H and r (msckf.py:540-544) --
     for (int k = 0; k < 3; ++k) {
         // norm of Hf[k:, k]
         double part = 0;
-        for (int i = k + tid; i < R4; i += 256) { double v = Hf[i * 3 + k]; part += v * v; }
-        red[tid] = part;
-        __syncthreads();
-        for (int s2 = 128; s2 > 0; s2 >>= 1) { if (tid < s2) red[tid] += red[tid + s2]; __syncthreads(); }
-        const double nrm = sqrt(red[0]);
-        __syncthreads();
+        for (int i = k + tid; i < R4; i += TEAM) { double v = Hf[i * 3 + k]; part += v * v; }
+        double nrm;
+        if (TEAM == 256) {
+            red[tid] = part;
+            team_sync<TEAM>();
+            for (int s2 = 128; s2 > 0; s2 >>= 1) { if (tid < s2) red[tid] += red[tid + s2]; team_sync<TEAM>(); }
+            nrm = sqrt(red[0]);
+            team_sync<TEAM>();
+        } else {
+            nrm = sqrt(wave_sum_f64(part));
+        }
         const double akk = Hf[k * 3 + k];
         const double alpha = akk >= 0 ? -nrm : nrm;
         const double v0 = akk - alpha;                     // v = x - alpha e1, stored in place in Hf[k:, k] (v0 kept apart)
         const double vtv = nrm * nrm - 2 * alpha * akk + alpha * alpha;      // |v|^2
         const double tau = vtv > 0 ? 2.0 / vtv : 0.0;
-        // columns to transform: remaining Hf columns (k+1..2), all C6 columns of H, and r  => C6 + (2-k) + 1 jobs
-        const int njobs = C6 + (2 - k) + 1;
-        for (int job = tid; job < njobs; job += 256) {
-            double* col; int stride;
-            if (job < C6) { col = H + job; stride = C6; }
-            else if (job < C6 + (2 - k)) { col = Hf + (k + 1 + job - C6); stride = 3; }
-            else { col = rr; stride = 1; }
+        // columns to transform: all C6 columns of H, the remaining Hf columns (k+1..2), r, and the R4 columns of G
+        auto reflect = [&](double* col, int stride) {
             double dot = v0 * col[k * stride];
             for (int i = k + 1; i < R4; ++i) dot += Hf[i * 3 + k] * col[i * stride];
             dot *= tau;
             col[k * stride] -= dot * v0;
             for (int i = k + 1; i < R4; ++i) col[i * stride] -= dot * Hf[i * 3 + k];
+        };
+        const int nfix = C6 + (2 - k) + 1, njobs = nfix + R4;
+        for (int job = tid; job < njobs; job += TEAM) {
+            if (job < C6) reflect(H + job, C6);
+            else if (job < C6 + (2 - k)) reflect(Hf + (k + 1 + job - C6), 3);
+            else if (job < nfix) reflect(rr, 1);
+            else reflect(S + (job - nfix), SP);
         }
-        __syncthreads();
+        team_sync<TEAM>();
+        for (int job = tid; job < R4; job += TEAM) reflect(S + job * SP, 1);       // ... and G from the right
+        team_sync<TEAM>();
     }
     // rows 3..R4-1 of H and r are A^T H_x and A^T r.  Write them out (dense row of width ld).
     const int row0 = a.row_off[f];
-    for (int i = tid; i < K * a.ld; i += 256) {
+    for (int i = tid; i < K * a.ld; i += TEAM) {
         const int rI = i / a.ld, c = i - rI * a.ld;
         Hout[(size_t)(row0 + rI) * a.ld + c] = 0.0;
     }
-    __syncthreads();
-    for (int i = tid; i < K * C6; i += 256) {
+    team_sync<TEAM>();
+    for (int i = tid; i < K * C6; i += TEAM) {
         const int rI = i / C6, c = i - rI * C6;
         Hout[(size_t)(row0 + rI) * a.ld + IMU_DIM + 6 * cidx[c / 6] + c % 6] = H[(3 + rI) * C6 + c];
     }
-    for (int i = tid; i < K; i += 256) rout[row0 + i] = rr[3 + i];
+    for (int i = tid; i < K; i += TEAM) rout[row0 + i] = rr[3 + i];
 
-    // ---- gating test (msckf.py:604-612): S = H' Psub H'^T + s^2 I, gamma = r'^T S^-1 r' -------------
-    for (int i0 = 0; i0 < K; i0 += 8) {
-        const int nr = min(8, K - i0);
-        __syncthreads();
-        for (int e = tid; e < nr * C6; e += 256) {
-            const int ri = e / C6, d = e - ri * C6;
-            const double* hrow = H + (3 + i0 + ri) * C6;
-            const int pd = IMU_DIM + 6 * cidx[d / 6] + d % 6;
-            double acc = 0;
-            for (int c = 0; c < C6; ++c) acc += hrow[c] * Pm[(size_t)(IMU_DIM + 6 * cidx[c / 6] + c % 6) * a.ld + pd];
-            Tc[ri * C6 + d] = acc;
-        }
-        __syncthreads();
-        for (int e = tid; e < nr * K; e += 256) {
-            const int ri = e / K, jj = e - ri * K;
-            const double* hrow = H + (3 + jj) * C6;
-            double acc = 0;
-            for (int d = 0; d < C6; ++d) acc += Tc[ri * C6 + d] * hrow[d];
-            S[(i0 + ri) * K + jj] = acc + ((i0 + ri) == jj ? a.obs_noise : 0.0);
-        }
-    }
-    __syncthreads();
+    // ---- gating test (msckf.py:604-612): S = H' Psub H'^T + s^2 I = (Q^T G Q)[3:, 3:] + s^2 I, gamma = r'^T S^-1 r' ----
+    double* Sg = S + 3 * SP + 3;                 // K x K, row pitch SP
+    for (int i = tid; i < K; i += TEAM) Sg[i * SP + i] += a.obs_noise;
+    team_sync<TEAM>();
     // Cholesky S = L L^T (lower, in place) and forward solve L y = r'
     for (int k = 0; k < K; ++k) {
-        if (tid == 0) S[k * K + k] = sqrt(S[k * K + k]);
-        __syncthreads();
-        const double dkk = S[k * K + k];
-        for (int i = k + 1 + tid; i < K; i += 256) S[i * K + k] /= dkk;
-        __syncthreads();
+        if (tid == 0) Sg[k * SP + k] = sqrt(Sg[k * SP + k]);
+        team_sync<TEAM>();
+        const double dkk = Sg[k * SP + k];
+        for (int i = k + 1 + tid; i < K; i += TEAM) Sg[i * SP + k] /= dkk;
+        team_sync<TEAM>();
         const int rem = K - k - 1;
-        for (int e = tid; e < rem * rem; e += 256) {
+        for (int e = tid; e < rem * rem; e += TEAM) {
             const int i = k + 1 + e / rem, jj = k + 1 + e % rem;
-            if (jj <= i) S[i * K + jj] -= S[i * K + k] * S[jj * K + k];
+            if (jj <= i) Sg[i * SP + jj] -= Sg[i * SP + k] * Sg[jj * SP + k];
         }
-        __syncthreads();
+        team_sync<TEAM>();
     }
     if (tid == 0) {
         double g = 0;
         for (int i = 0; i < K; ++i) {
             double v = rr[3 + i];
-            for (int jj = 0; jj < i; ++jj) v -= S[i * K + jj] * red[jj];
-            v /= S[i * K + i];
+            for (int jj = 0; jj < i; ++jj) v -= Sg[i * SP + jj] * red[jj];
+            v /= Sg[i * SP + i];
             red[i] = v;                          // K <= 77 < 256
             g += v * v;
         }
         a.gamma[f] = g;
         a.pass[f] = g < a.chi2[a.dof[f]] ? 1 : 0;
     }
+}
+
+// Launch `cnt` features (a.feat_list or 0..cnt-1) whose tracks hold at most Mx observations.
+static int launch_feature_kernel(FeatArgs a, int cnt, int Mx, hipStream_t st)
+{
+    a.Mmax = Mx; a.n_list = cnt;
+    const size_t per = (feature_lds_bytes(Mx) + 7) / 8 * 8;
+    a.team_doubles = (int)(per / 8);
+    if (per > 160 * 1024) { av_set_error("MSCKF feature blocks: %d observations per feature need %zu B of LDS", Mx, per); return AV_E_CAPACITY; }
+    if (Mx <= 4 && !getenv("AV_FEATURE_BLOCK_TEAMS")) {        // (env: A/B and debugging aid, forces one workgroup per feature)
+        const size_t lds = per * 4;
+        AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(feature_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(feature_kernel<64>, dim3((cnt + 3) / 4), dim3(256), lds, st, a);
+    } else {
+        AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(feature_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)per));
+        hipLaunchKernelGGL(feature_kernel<256>, dim3(cnt), dim3(256), per, st, a);
+    }
+    AV_LAUNCH_CHECK();
+    return AV_OK;
 }
 
 // ================================================================================================
@@ -1139,14 +1212,8 @@ AV_EXPORT int av_msckf_feature_blocks(av_msckf* c, int n_feat, int n_cam, int ma
     a.obs_noise = obs_noise; a.Hout = c->Hblk; a.rout = c->rblk; a.gamma = gamma_dev; a.pass = pass_dev; a.Mmax = max_obs;
     a.feat_stream = nullptr; a.stream_ncam = nullptr; a.stream_gravity = nullptr; a.cam_stride = 0; a.p_stride = a.h_stride = a.r_stride = 0;
     a.feat_list = nullptr;
-    const int Mx = max_obs;
-    size_t lds = sizeof(double) * ((size_t)(4 * Mx) * (6 * Mx) + (4 * Mx) * 3 + 4 * Mx + (size_t)(4 * Mx) * (4 * Mx) + 8 * (6 * Mx) + 256) + sizeof(int) * Mx + 16;
-    if (lds > 160 * 1024) { av_set_error("av_msckf_feature_blocks: %d observations per feature need %zu B of LDS", max_obs, lds); return AV_E_CAPACITY; }
     AV_HIP(hipSetDevice(c->device));
-    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(feature_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(feature_kernel, dim3(n_feat), dim3(256), lds, (hipStream_t)stream, a);
-    AV_LAUNCH_CHECK();
-    return AV_OK;
+    return launch_feature_kernel(a, n_feat, max_obs, (hipStream_t)stream);
 }
 
 AV_EXPORT int av_msckf_update(av_msckf* c, const int32_t* blk_row_dev, const int32_t* blk_len_dev, int n_blk, int total_rows,
