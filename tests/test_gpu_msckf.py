@@ -126,9 +126,12 @@ def test_end_to_end_matches_reference_golden(dropin, cfg, name):
     flt.close()
 
 
-def test_batched_filters_match_reference_golden_and_oracle(cfg):
+@pytest.mark.parametrize('groups', [1, 2])
+def test_batched_filters_match_reference_golden_and_oracle(cfg, groups, monkeypatch):
     """Three independent streams stepped together by the C++/HIP batched filter: stream 0 reproduces the
-    reference's own golden run; all streams follow the numpy oracle frame by frame."""
+    reference's own golden run; all streams follow the numpy oracle frame by frame.  groups=2 splits the batch
+    into two concurrently stepped stream groups (streams {0,1} and {2}), as large batches are by default."""
+    monkeypatch.setenv('AV_MSCKF_GROUPS', str(groups))
     from oracle.msckf_np import OracleMSCKF
     from uav_airvision_amd.msckf_ops import BatchedMSCKF
     from uav_airvision_amd.synth import SyntheticFeatureStream

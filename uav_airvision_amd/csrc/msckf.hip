@@ -511,19 +511,21 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
     }
 }
 
+static int msckf_lds_opt_in();       // raises the dynamic-LDS limit of every kernel below once per process
+
 // Launch `cnt` features (a.feat_list or 0..cnt-1) whose tracks hold at most Mx observations.
 static int launch_feature_kernel(FeatArgs a, int cnt, int Mx, hipStream_t st)
 {
+    int rc0 = msckf_lds_opt_in();
+    if (rc0) return rc0;
     a.Mmax = Mx; a.n_list = cnt;
     const size_t per = (feature_lds_bytes(Mx) + 7) / 8 * 8;
     a.team_doubles = (int)(per / 8);
     if (per > 160 * 1024) { av_set_error("MSCKF feature blocks: %d observations per feature need %zu B of LDS", Mx, per); return AV_E_CAPACITY; }
     if (Mx <= 4 && !getenv("AV_FEATURE_BLOCK_TEAMS")) {        // (env: A/B and debugging aid, forces one workgroup per feature)
         const size_t lds = per * 4;
-        AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(feature_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(feature_kernel<64>, dim3((cnt + 3) / 4), dim3(256), lds, st, a);
     } else {
-        AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(feature_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)per));
         hipLaunchKernelGGL(feature_kernel<256>, dim3(cnt), dim3(256), per, st, a);
     }
     AV_LAUNCH_CHECK();
@@ -1034,6 +1036,27 @@ __global__ __launch_bounds__(UT) void update_batch_kernel(const UpdArgs* arr)
 {
     if (arr[blockIdx.x].m > 0) update_body(arr[blockIdx.x]);          // block-uniform
 }
+// The kernels with dynamic LDS are allowed the whole 160 KB once, up front: the limit is process-wide state, and the
+// stream groups of the batched filter launch concurrently from several host threads (a per-launch hipFuncSetAttribute
+// with the launch's own size could lower the limit under another thread's launch).
+static int msckf_lds_opt_in()
+{
+    static const int rc = [] {
+        const int lim = 160 * 1024;
+        const void* fns[4] = {reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
+                              reinterpret_cast<const void*>(update_kernel), reinterpret_cast<const void*>(update_batch_kernel)};
+        for (const void* f : fns) {
+            // the dynamic limit excludes the kernel's static LDS (a few hundred bytes in the update kernels)
+            hipFuncAttributes at;
+            hipError_t e = hipFuncGetAttributes(&at, f);
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim - (int)at.sharedSizeBytes);
+            if (e != hipSuccess) { av_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e)); return (int)AV_E_HIP; }
+        }
+        return (int)AV_OK;
+    }();
+    return rc;
+}
+
 // diag(P)[12..14] of every stream (online_reset, msckf.py:829-835)
 __global__ void pos_var_kernel(const double* P, size_t p_stride, int ld, int S, double* out)
 {
@@ -1237,7 +1260,7 @@ AV_EXPORT int av_msckf_update(av_msckf* c, const int32_t* blk_row_dev, const int
     const int k = total_rows > a.nc ? a.nc : total_rows;
     size_t lds = sizeof(double) * ((size_t)k * (k + 1) / 2 + 8 + 2 * (size_t)total_rows);
     if (lds > 160 * 1024) { av_set_error("av_msckf_update: %d rows need %zu B of LDS", total_rows, lds); return AV_E_CAPACITY; }
-    AV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { int rc0 = msckf_lds_opt_in(); if (rc0) return rc0; }
     hipLaunchKernelGGL(update_kernel, dim3(1), dim3(UT), lds, st, a);
     AV_LAUNCH_CHECK();
     AV_HIP(hipMemcpyAsync(dx_host, c->dx, sizeof(double) * c->n, hipMemcpyDeviceToHost, st));
