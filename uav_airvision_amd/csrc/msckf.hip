@@ -44,11 +44,30 @@ __device__ __forceinline__ void quat_to_rot(const double* qin, double* R)
     R[6] = 2 * w * y + 2 * z * x;  R[7] = -2 * w * x + 2 * z * y;  R[8] = c + 2 * z * z;
 }
 
+// Sum over the 64 lanes, returned to every lane.  Four DPP butterfly steps inside each 16-lane row (two v_mov_dpp on
+// the halves + one v_add_f64 each), then the four row sums are read through SGPRs -- an order of magnitude less latency
+// than six dependent ds_bpermute round trips, and this reduction sits on the critical path of every Householder step.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double lane_f64(double v, int lane)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v += dpp_f64<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);      // row_half_mirror
+    v += dpp_f64<0x140>(v);      // row_mirror
+    return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
 }
 
 // ================================================================================================
@@ -793,12 +812,120 @@ __device__ __forceinline__ double block_sum(double v, double* red)
     return s;
 }
 
-__device__ __forceinline__ void update_body(const UpdArgs& a)
+
+// Thin Householder QR of the stacked [H | r] held entirely in registers.  Column c lives in wavefront c % 16 (slot
+// c / 16), row i in lane i % 64 (slot i / 64): CPW x RPL doubles per lane, so 16*CPW >= nc+1 and 64*RPL >= m.
+// Per reflector: the owner wavefront norms its column and publishes v (LDS, double buffered) and (v0, tau); after ONE
+// barrier every wavefront applies it to its own columns without touching memory.  The generic path below keeps the
+// columns in global memory (L2) and pays two dependent round trips per reflector.
+template <int CPW, int RPL>
+__device__ __forceinline__ void qr_in_registers(const UpdArgs& a, int m, int nc, const int* srcrow, double* vb0, double* vb1, double* qsc,
+                                                double* Wt, size_t ldt, double* rcol)
 {
-    extern __shared__ double Lp[];               // packed lower triangle of S / its Cholesky factor: k(k+1)/2
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double x[CPW][RPL];
+#pragma unroll
+    for (int l = 0; l < CPW; ++l) {
+        const int c = wave + 16 * l;
+#pragma unroll
+        for (int t = 0; t < RPL; ++t) {
+            const int row = lane + 64 * t;
+            double v = 0.0;
+            if (row < m && c <= nc) v = c < nc ? a.Hsrc[(size_t)srcrow[row] * a.ld + a.cols[c]] : a.rsrc[srcrow[row]];
+            x[l][t] = v;
+        }
+    }
+    __syncthreads();                                   // srcrow shares its LDS with the reflector buffers
+    if (a.prof && tid == 0) a.prof[1] = __builtin_amdgcn_s_memrealtime();     // diagnostic: 'gather' ends once the columns sit in registers
+    for (int j = 0; j < nc; ++j) {
+        double* vb = (j & 1) ? vb1 : vb0;
+        double* sc = qsc + 2 * (j & 1);
+        if (wave == (j & 15)) {
+            const int lj = j >> 4, tj = j >> 6;
+            double part = 0, cand = 0;
+#pragma unroll
+            for (int l = 0; l < CPW; ++l) if (l == lj) {
+#pragma unroll
+                for (int t = 0; t < RPL; ++t) {
+                    const int row = lane + 64 * t;
+                    if (row >= j) part += x[l][t] * x[l][t];
+                    if (t == tj) cand = x[l][t];
+                }
+            }
+            const double nrm2 = wave_sum_f64(part);
+            const double ajj = __shfl(cand, j & 63, 64);
+            const double nrm = sqrt(nrm2);
+            const double alpha = ajj >= 0 ? -nrm : nrm;
+            const double vtv = nrm2 - 2 * alpha * ajj + alpha * alpha;
+            if (lane == 0) { sc[0] = ajj - alpha; sc[1] = vtv > 0 ? 2.0 / vtv : 0.0; }
+#pragma unroll
+            for (int l = 0; l < CPW; ++l) if (l == lj) {
+#pragma unroll
+                for (int t = 0; t < RPL; ++t) {
+                    const int row = lane + 64 * t;
+                    if (row > j && row < m) vb[row] = x[l][t];
+                    if (row == j) x[l][t] = alpha; else if (row > j) x[l][t] = 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        const double v0 = sc[0], tau = sc[1];
+        auto vv = [&](int t) -> double { const int row = lane + 64 * t; return row == j ? v0 : ((row > j && row < m) ? vb[row] : 0.0); };
+        if (RPL <= 8) {
+            // few rows per lane: v stays in registers for all CPW columns (re-reading it per column makes the step LDS-bandwidth bound)
+            double v[RPL <= 8 ? RPL : 1];
+#pragma unroll
+            for (int t = 0; t < (RPL <= 8 ? RPL : 1); ++t) v[t] = vv(t);
+#pragma unroll
+            for (int l = 0; l < CPW; ++l) {
+                const int c = wave + 16 * l;
+                if (c > j && c <= nc) {                    // wavefront-uniform
+                    double dot = 0;
+#pragma unroll
+                    for (int t = 0; t < (RPL <= 8 ? RPL : 1); ++t) dot += v[t] * x[l][t];
+                    dot = wave_sum_f64(dot) * tau;
+#pragma unroll
+                    for (int t = 0; t < (RPL <= 8 ? RPL : 1); ++t) x[l][t] -= dot * v[t];
+                }
+            }
+        } else {
+            // many rows, one or two columns per lane: v is re-read from LDS (keeping it next to x would double the footprint)
+#pragma unroll
+            for (int l = 0; l < CPW; ++l) {
+                const int c = wave + 16 * l;
+                if (c > j && c <= nc) {
+                    double dot = 0;
+#pragma unroll
+                    for (int t = 0; t < RPL; ++t) dot += vv(t) * x[l][t];
+                    dot = wave_sum_f64(dot) * tau;
+#pragma unroll
+                    for (int t = 0; t < RPL; ++t) x[l][t] -= dot * vv(t);
+                }
+            }
+        }
+    }
+    // R (upper triangular, zeros below the diagonal) and Q^T r: the first nc rows of every column
+#pragma unroll
+    for (int l = 0; l < CPW; ++l) {
+        const int c = wave + 16 * l;
+        if (c <= nc) {
+            double* dst = c < nc ? Wt + (size_t)c * ldt : rcol;
+#pragma unroll
+            for (int t = 0; t < RPL; ++t) { const int row = lane + 64 * t; if (row < nc) dst[row] = x[l][t]; }
+        }
+    }
+    __syncthreads();
+}
+
+// The stacked update runs as two kernels per launch group: update_front (row map, gather, thin QR -> rows 0..k-1 of
+// [H_thin | r_thin] in W) and update_back (gain, covariance).  Separate kernels keep the register-resident QR and the
+// 4x4-tiled products out of each other's register allocation (fused, the compiler spilled in every phase).
+__device__ __forceinline__ void update_front(const UpdArgs& a)
+{
+    extern __shared__ double Lp[];               // front: row map / scan scratch, then the two reflector buffers (2 m doubles)
     __shared__ double red[UT / 64];
     __shared__ double vnorm[3];
-    const int tid = threadIdx.x, n = a.n, m = a.m;
+    const int tid = threadIdx.x, m = a.m;
     // Column compression: the stacked Jacobian is zero outside the 6-wide blocks of the camera states that the
     // stacked features were observed from (the 21 IMU columns are always zero, msckf.py:535).  Only those nc
     // columns (a.cols, ascending) are factorised.  Replacing (H, r) by (R, Q^T r) of ANY thin QR of H leaves
@@ -810,30 +937,57 @@ __device__ __forceinline__ void update_body(const UpdArgs& a)
     const size_t ldt = a.ldt;                    // W is stored TRANSPOSED: Wt[q * ldt + i] = H[i][cols[q]]; r lives in row nc.
     double* Wt = a.W;                            // Column operations of the QR are then contiguous (coalesced) row segments.
     double* rcol = Wt + (size_t)nc * ldt;
-    // 1. gather the gated feature blocks into Wt
+    // 1. row map of the stacked matrix: srcrow[i] = row of Hsrc / rsrc that becomes stacked row i (inclusive scan of the
+    //    block lengths).  The map and the scan scratch live where the QR keeps its reflector buffers later.
+    __shared__ double qsc[4];
+    int* srcrow = reinterpret_cast<int*>(Lp);
     {
-        int row = 0;
-        for (int b = 0; b < a.n_blk; ++b) {
-            const int r0 = a.blk_row[b], len = a.blk_len[b];
-            for (int i = tid; i < len * nc; i += UT) {
-                int r = i / nc, q = i - r * nc;
-                Wt[(size_t)q * ldt + row + r] = a.Hsrc[(size_t)(r0 + r) * a.ld + a.cols[q]];
-            }
-            for (int r = tid; r < len; r += UT) rcol[row + r] = a.rsrc[r0 + r];
-            row += len;
+        int* scan = srcrow + m;                          // n_blk <= m (every block has at least one row); host checks n_blk <= 4 * UT
+        const int nb = a.n_blk;
+        for (int b = tid; b < nb; b += UT) scan[b] = a.blk_len[b];
+        __syncthreads();
+        for (int off = 1; off < nb; off <<= 1) {
+            int tmp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int b = tid + u * UT; tmp[u] = (b < nb && b >= off) ? scan[b - off] : 0; }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int b = tid + u * UT; if (b < nb) scan[b] += tmp[u]; }
+            __syncthreads();
         }
+        for (int b = tid; b < nb; b += UT) {
+            const int len = a.blk_len[b], r0 = a.blk_row[b], d0 = scan[b] - len;
+            for (int r = 0; r < len; ++r) srcrow[d0 + r] = r0 + r;
+        }
+        __syncthreads();
+    }
+    const bool qr_regs = m > nc && ((nc + 1 <= 128 && m <= 256) || (nc + 1 <= 64 && m <= 512) || (nc + 1 <= 32 && m <= 1024) || (nc + 1 <= 16 && m <= 2048));
+    if (!qr_regs) {
+        // gather the gated feature blocks into Wt (coalesced writes along a column)
+        for (int i = tid; i < m * nc; i += UT) {
+            const int q = i / m, row = i - q * m;
+            Wt[(size_t)q * ldt + row] = a.Hsrc[(size_t)srcrow[row] * a.ld + a.cols[q]];
+        }
+        for (int row = tid; row < m; row += UT) rcol[row] = a.rsrc[srcrow[row]];
     }
     __syncthreads();
     stamp(1);
     // 2. thin QR by Householder when m > nc; afterwards rows 0..k-1 hold [H_thin | r_thin]
-    int k = m;
-    if (m > nc) {
-        k = nc;
+    if (qr_regs) {
+        double* vb0 = Lp;
+        if (nc + 1 <= 128 && m <= 128) qr_in_registers<8, 2>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
+        else if (nc + 1 <= 128 && m <= 192) qr_in_registers<8, 3>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
+        else if (nc + 1 <= 128 && m <= 256) qr_in_registers<8, 4>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
+        else if (nc + 1 <= 64 && m <= 512) qr_in_registers<4, 8>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
+        else if (nc + 1 <= 32 && m <= 1024) qr_in_registers<2, 16>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
+        else if (nc + 1 <= 16 && m <= 1536) qr_in_registers<1, 24>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
+        else qr_in_registers<1, 32>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
+    } else if (m > nc) {
         const int wave = tid >> 6, lane = tid & 63, nw = UT / 64;
         // Two LDS buffers hold the current and the next reflector column.  The wavefront that updates column j+1
         // in step j also accumulates its squared norm and stages it as the next reflector, so a Householder step
         // costs one pass over the trailing columns and two barriers (no separate norm pass).
-        double* vbuf[2] = {Lp + (size_t)nc * (nc + 1) / 2 + 8, Lp + (size_t)nc * (nc + 1) / 2 + 8 + m};
+        double* vbuf[2] = {Lp, Lp + m};
         {
             const double* c0p = Wt;
             double part = 0;
@@ -896,6 +1050,18 @@ __device__ __forceinline__ void update_body(const UpdArgs& a)
         __syncthreads();
     }
     stamp(2);
+}
+
+__device__ __forceinline__ void update_back(const UpdArgs& a)
+{
+    extern __shared__ double Lp[];               // packed lower triangle of S / its Cholesky factor: k(k+1)/2
+    const int tid = threadIdx.x, n = a.n, m = a.m, nc = a.nc;
+    auto stamp = [&](int i) { if (a.prof && tid == 0) a.prof[i] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(7);
+    const size_t ldt = a.ldt;
+    double* Wt = a.W;
+    double* rcol = Wt + (size_t)nc * ldt;
+    const int k = m > nc ? nc : m;
     // 3. T = H_thin P  (k x n):  T[r][c] = sum_q Wt[q][r] P[cols[q]][c].  Register-tiled: each thread owns a 4x4
     //    micro-tile, per q it loads 4 contiguous values of each operand (32 B) and does 16 FMAs.
     {
@@ -952,42 +1118,56 @@ __device__ __forceinline__ void update_body(const UpdArgs& a)
     }
     __syncthreads();
     stamp(3);
-    // 5. Cholesky in LDS
+    // 5. Cholesky in LDS, right-looking with the column scaling deferred: step j only subtracts a_rj a_cj / d_j from the
+    //    trailing block (one barrier per column instead of three); columns are divided by sqrt(d_j) in one pass at the end.
     for (int j = 0; j < k; ++j) {
-        const int jj = j * (j + 1) / 2 + j;
-        if (tid == 0) Lp[jj] = sqrt(Lp[jj]);
-        __syncthreads();
-        const double d = Lp[jj];
-        for (int i = j + 1 + tid; i < k; i += UT) Lp[i * (i + 1) / 2 + j] /= d;
-        __syncthreads();
-        const int rem = k - j - 1;
-        for (int e = tid; e < rem * rem; e += UT) {
-            const int r = j + 1 + e / rem, c = j + 1 + e % rem;
-            if (c <= r) Lp[r * (r + 1) / 2 + c] -= Lp[r * (r + 1) / 2 + j] * Lp[c * (c + 1) / 2 + j];
+        const double inv = 1.0 / Lp[j * (j + 1) / 2 + j];
+        // 32 x 32 thread grid over the trailing block (no integer division by the shrinking block size)
+        for (int r = j + 1 + (tid >> 5); r < k; r += UT / 32) {
+            const double lrj = Lp[r * (r + 1) / 2 + j] * inv;
+            for (int c = j + 1 + (tid & 31); c <= r; c += 32) Lp[r * (r + 1) / 2 + c] -= lrj * Lp[c * (c + 1) / 2 + j];
         }
         __syncthreads();
     }
+    for (int e = tid; e < k * k; e += UT) {
+        const int r = e / k, c = e - r * k;
+        if (c < r) Lp[r * (r + 1) / 2 + c] /= sqrt(Lp[c * (c + 1) / 2 + c]);
+    }
+    __syncthreads();
+    for (int j = tid; j < k; j += UT) Lp[j * (j + 1) / 2 + j] = sqrt(Lp[j * (j + 1) / 2 + j]);
+    __syncthreads();
     stamp(4);
     // 6. Y = L^-1 [T | r_thin]: forward substitution only, one thread per right-hand side (n columns of T plus r).
     //    With S = L L^T:  K r = T^T S^-1 r = Y^T y_r  and  (I - K H) P = P - T^T S^-1 T = P - Y^T Y   (msckf.py:565-602);
     //    the backward substitution of an explicit K^T = S^-1 T is not needed.  Y overwrites Kt, y_r overwrites rcol.
+    //    Blocked by 8 rows: the 8 partial sums share every load of an already solved y (one global load feeds 8 FMAs;
+    //    the L entries are LDS broadcasts, all right-hand sides read the same address).
     for (int c = tid; c <= n; c += UT) {
         double* y = c < n ? a.Kt + c : rcol;
         const double* src = c < n ? a.T + c : rcol;
         const size_t st_ = c < n ? (size_t)a.ld : 1;
-        for (int i = 0; i < k; ++i) {
-            double v = src[(size_t)i * st_];
-            const double* Lrow = Lp + (size_t)i * (i + 1) / 2;
-            int q = 0;
-            for (; q + 8 <= i; q += 8) {
-                double yy[8];
+        for (int i0 = 0; i0 < k; i0 += 8) {
+            double acc[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) yy[u] = y[(size_t)(q + u) * st_];
+            for (int u = 0; u < 8; ++u) acc[u] = i0 + u < k ? src[(size_t)(i0 + u) * st_] : 0.0;
+            const double* Lr[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v -= Lrow[q + u] * yy[u];
+            for (int u = 0; u < 8; ++u) { const int i = min(i0 + u, k - 1); Lr[u] = Lp + (size_t)i * (i + 1) / 2; }
+#pragma unroll 4
+            for (int q = 0; q < i0; ++q) {
+                const double yq = y[(size_t)q * st_];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] -= Lr[u][q] * yq;
             }
-            for (; q < i; ++q) v -= Lrow[q] * y[(size_t)q * st_];
-            y[(size_t)i * st_] = v / Lrow[i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u < k) {
+#pragma unroll
+                    for (int w = 0; w < u; ++w) acc[u] -= Lr[u][i0 + w] * acc[w];
+                    acc[u] /= Lr[u][i0 + u];
+                    y[(size_t)(i0 + u) * st_] = acc[u];
+                }
+            }
         }
     }
     __syncthreads();
@@ -1031,11 +1211,21 @@ __device__ __forceinline__ void update_body(const UpdArgs& a)
     __syncthreads();
     stamp(6);
 }
-__global__ __launch_bounds__(UT) void update_kernel(UpdArgs a) { update_body(a); }
-__global__ __launch_bounds__(UT) void update_batch_kernel(const UpdArgs* arr)
+__global__ __launch_bounds__(UT) void update_front_kernel(UpdArgs a) { update_front(a); }
+__global__ __launch_bounds__(UT) void update_back_kernel(UpdArgs a) { update_back(a); }
+__global__ __launch_bounds__(UT) void update_front_batch_kernel(const UpdArgs* __restrict__ arr)
 {
-    if (arr[blockIdx.x].m > 0) update_body(arr[blockIdx.x]);          // block-uniform
+    const UpdArgs a = arr[blockIdx.x];                                 // block-uniform: lives in scalar registers
+    if (a.m > 0) update_front(a);
 }
+__global__ __launch_bounds__(UT) void update_back_batch_kernel(const UpdArgs* __restrict__ arr)
+{
+    const UpdArgs a = arr[blockIdx.x];
+    if (a.m > 0) update_back(a);
+}
+// LDS of the two halves for a stream with m stacked rows over nc columns
+static inline size_t update_front_lds(int m) { return sizeof(double) * (2 * (size_t)m + 8); }
+static inline size_t update_back_lds(int m, int nc) { const size_t k = m > nc ? nc : m; return sizeof(double) * (k * (k + 1) / 2 + 8); }
 // The kernels with dynamic LDS are allowed the whole 160 KB once, up front: the limit is process-wide state, and the
 // stream groups of the batched filter launch concurrently from several host threads (a per-launch hipFuncSetAttribute
 // with the launch's own size could lower the limit under another thread's launch).
@@ -1044,7 +1234,14 @@ static int msckf_lds_opt_in()
     static const int rc = [] {
         const int lim = 160 * 1024;
         const void* fns[4] = {reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
-                              reinterpret_cast<const void*>(update_kernel), reinterpret_cast<const void*>(update_batch_kernel)};
+                              reinterpret_cast<const void*>(update_front_kernel), reinterpret_cast<const void*>(update_front_batch_kernel)};
+        const void* fns2[2] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel)};
+        for (const void* f : fns2) {
+            hipFuncAttributes at;
+            hipError_t e = hipFuncGetAttributes(&at, f);
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim - (int)at.sharedSizeBytes);
+            if (e != hipSuccess) { av_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e)); return (int)AV_E_HIP; }
+        }
         for (const void* f : fns) {
             // the dynamic limit excludes the kernel's static LDS (a few hundred bytes in the update kernels)
             hipFuncAttributes at;
@@ -1257,11 +1454,12 @@ AV_EXPORT int av_msckf_update(av_msckf* c, const int32_t* blk_row_dev, const int
     AV_HIP(hipMemcpyAsync(c->cols_dev, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice, st));
     AV_HIP(hipStreamSynchronize(st));
     a.cols = c->cols_dev; a.nc = (int)cols.size();
-    const int k = total_rows > a.nc ? a.nc : total_rows;
-    size_t lds = sizeof(double) * ((size_t)k * (k + 1) / 2 + 8 + 2 * (size_t)total_rows);
-    if (lds > 160 * 1024) { av_set_error("av_msckf_update: %d rows need %zu B of LDS", total_rows, lds); return AV_E_CAPACITY; }
+    const size_t lds_f = update_front_lds(total_rows), lds_b = update_back_lds(total_rows, a.nc);
+    if (lds_f > 160 * 1024 || lds_b > 160 * 1024) { av_set_error("av_msckf_update: %d rows need %zu B of LDS", total_rows, lds_f > lds_b ? lds_f : lds_b); return AV_E_CAPACITY; }
+    if (n_blk > 4 * UT) { av_set_error("av_msckf_update: %d blocks exceed %d", n_blk, 4 * UT); return AV_E_CAPACITY; }
     { int rc0 = msckf_lds_opt_in(); if (rc0) return rc0; }
-    hipLaunchKernelGGL(update_kernel, dim3(1), dim3(UT), lds, st, a);
+    hipLaunchKernelGGL(update_front_kernel, dim3(1), dim3(UT), lds_f, st, a);
+    hipLaunchKernelGGL(update_back_kernel, dim3(1), dim3(UT), lds_b, st, a);
     AV_LAUNCH_CHECK();
     AV_HIP(hipMemcpyAsync(dx_host, c->dx, sizeof(double) * c->n, hipMemcpyDeviceToHost, st));
     AV_HIP(hipStreamSynchronize(st));
