@@ -566,7 +566,11 @@ struct PropArgs {
     double noise[4];                 // gyro, gyro_bias, acc, acc_bias (continuous)
 };
 
-__device__ __forceinline__ void propagate_body(const PropArgs& a)
+// P11s / PhiT (LDS, both or neither): batched mode.  The IMU block of P lives in P11s across the samples of one frame
+// and the transition matrices are accumulated into PhiT, so the cross block P12 <- Phi P12 is applied ONCE per frame
+// with the product of the frame's transition matrices instead of once per IMU sample (same map; ten passes over the
+// 21 x 6N block in global memory become one).
+__device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s = nullptr, double* PhiT = nullptr)
 {
     __shared__ double F[IMU_DIM * IMU_DIM], F2[IMU_DIM * IMU_DIM], Phi[IMU_DIM * IMU_DIM], G[IMU_DIM * 12], T[IMU_DIM * IMU_DIM], Q[IMU_DIM * IMU_DIM];
     __shared__ double Rwi[9], Rnull[9], Rnew[9], u[3], sv[3], w1[3], w2[3];
@@ -656,7 +660,8 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a)
     // P11 <- Phi P11 Phi^T + Q
     for (int i = tid; i < N * N; i += 256) {
         int r = i / N, c = i - r * N; double s = 0;
-        for (int k = 0; k < N; ++k) s += Phi[r * N + k] * a.P[(size_t)k * a.ld + c];
+        if (P11s) { for (int k = 0; k < N; ++k) s += Phi[r * N + k] * P11s[k * N + c]; }
+        else      { for (int k = 0; k < N; ++k) s += Phi[r * N + k] * a.P[(size_t)k * a.ld + c]; }
         F2[i] = s;                                                              // Phi P11
     }
     __syncthreads();
@@ -666,6 +671,19 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a)
         F[i] = s + Q[i];
     }
     __syncthreads();
+    if (P11s) {
+        // batched: symmetrised IMU block back to LDS ((P + P^T)/2 per sample, msckf.py:334-335), PhiT <- Phi PhiT
+        for (int i = tid; i < N * N; i += 256) {
+            int r = i / N, c = i - r * N; double s = 0;
+            for (int k = 0; k < N; ++k) s += Phi[r * N + k] * PhiT[k * N + c];
+            F2[i] = s;
+            P11s[i] = (F[r * N + c] + F[c * N + r]) / 2.;
+        }
+        __syncthreads();
+        for (int i = tid; i < N * N; i += 256) PhiT[i] = F2[i];
+        __syncthreads();
+        return;
+    }
     // P12 <- Phi P12 (computed from the OLD P12 into scratch rows of T in chunks), P21 = P12^T
     const int nc = a.n - N;
     for (int c0 = 0; c0 < nc; c0 += N) {
@@ -694,10 +712,40 @@ __global__ __launch_bounds__(256) void propagate_kernel(PropArgs a) { propagate_
 // batched: block b applies samples first[b] .. first[b+1]-1 in order (one stream per block)
 __global__ __launch_bounds__(256) void propagate_batch_kernel(const PropArgs* arr, const int* first)
 {
-    for (int i = first[blockIdx.x]; i < first[blockIdx.x + 1]; ++i) {
-        propagate_body(arr[i]);
-        __syncthreads();
+    __shared__ double P11s[IMU_DIM * IMU_DIM], PhiT[IMU_DIM * IMU_DIM];
+    const int i0 = first[blockIdx.x], i1 = first[blockIdx.x + 1];
+    if (i0 >= i1) return;                                   // block-uniform
+    const int tid = threadIdx.x, N = IMU_DIM;
+    double* P = arr[i0].P; const int n = arr[i0].n, ld = arr[i0].ld;
+    for (int i = tid; i < N * N; i += 256) { int r = i / N, c = i - r * N; P11s[i] = P[(size_t)r * ld + c]; PhiT[i] = r == c ? 1.0 : 0.0; }
+    __syncthreads();
+    for (int i = i0; i < i1; ++i) propagate_body(arr[i], P11s, PhiT);
+    // cross block with the frame's accumulated transition: every element of the new block is formed in registers
+    // from the old one before anything is overwritten
+    const int nc = n - N, tot = N * nc;
+    constexpr int PER = (IMU_DIM * 6 * 31 + 255) / 256;     // up to 31 camera states
+    double acc[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = tid + 256 * u;
+        double s = 0;
+        if (e < tot) {
+            const int r = e / nc, c = e - r * nc;
+            for (int k = 0; k < N; ++k) s += PhiT[r * N + k] * P[(size_t)k * ld + N + c];
+        }
+        acc[u] = s;
     }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int e = tid + 256 * u;
+        if (e < tot) {
+            const int r = e / nc, c = e - r * nc;
+            P[(size_t)r * ld + N + c] = acc[u];
+            P[(size_t)(N + c) * ld + r] = acc[u];
+        }
+    }
+    for (int i = tid; i < N * N; i += 256) { int r = i / N, c = i - r * N; P[(size_t)r * ld + c] = P11s[i]; }
 }
 
 // ================================================================================================
