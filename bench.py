@@ -92,7 +92,7 @@ def cpu_baseline(cfg, with_msckf, budget_s=10.0, max_frames=400):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--streams', type=int, default=512, help='independent stereo streams per GPU')
     ap.add_argument('--unique', type=int, default=4, help='distinct rendered streams (replicated with per-stream noise)')
@@ -191,15 +191,38 @@ def main():
         msckf_s[0] += time.perf_counter() - t1
 
     def run_pipelined(k_begin, k_end):
-        """Full path for frames [k_begin, k_end): the front-end of frame k+1 is enqueued before the (host-blocking)
-        filter step of frame k, so the two overlap on the GPU and with the host bookkeeping."""
-        run_fe(k_begin)
-        for k in range(k_begin, k_end):
-            ids_h, uv_h, n_h = eng.read_features_raw()          # D2H of frame k (synchronises the front-end stream)
-            ids_c, uv_c, n_c = ids_h.copy(), uv_h.copy(), n_h.copy()
-            if k + 1 < k_end:
-                run_fe(k + 1)
-            run_filter(k, ids_c, uv_c, n_c)
+        """Full path for frames [k_begin, k_end), organised like the reference's VIO (vio.py:24-76: image thread ->
+        feature queue -> filter thread): this thread drives the front-end and hands every frame's feature message to a
+        filter thread through a bounded queue, so the front-end of later frames overlaps the (host-blocking) filter step
+        of earlier ones.  The timed region ends when the last filter step has returned."""
+        import queue, threading
+        q = queue.Queue(maxsize=2)
+        err = []
+
+        def filter_loop():
+            torch.cuda.set_device(dev)
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                try:
+                    if not err:
+                        run_filter(*item)
+                except Exception as e:          # surfaced by the main thread after the join
+                    err.append(e)
+
+        th = threading.Thread(target=filter_loop, name='msckf')
+        th.start()
+        try:
+            for k in range(k_begin, k_end):
+                run_fe(k)
+                ids_h, uv_h, n_h = eng.read_features_raw()      # D2H of frame k (synchronises the front-end stream)
+                q.put((k, ids_h.copy(), uv_h.copy(), n_h.copy()))
+        finally:
+            q.put(None)
+            th.join()
+        if err:
+            raise err[0]
 
     def run(k, filt=True):
         run_fe(k)
