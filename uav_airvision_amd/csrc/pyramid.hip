@@ -33,30 +33,37 @@ __device__ __forceinline__ uint8_t* pyr_of(const PyrArgs& a, int img)
     return a.pyr_base + s * a.stream_stride + (cam == 0 ? a.slot0 : a.slot1) * a.slot_stride;
 }
 
-// level 0: copy the tightly packed input image into the padded level, frame included.
+// level 0: copy the tightly packed input image into the padded level, frame included.  One thread writes 16 bytes;
+// chunks that lie inside the image (all but the 16-pixel frame columns) are one 16-byte load when rows are 16-aligned.
 __global__ __launch_bounds__(256) void pad_level0_kernel(PyrArgs a)
 {
     const int w = a.g.w[0], h = a.g.h[0], pitch = a.g.pitch[0];
-    const int quads_per_row = pitch >> 2;
+    const int chunks_per_row = pitch >> 4;                   // pitch is a multiple of 16
     const int ph = h + 2 * AV_PYR_BORDER;
     int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= quads_per_row * ph) return;
-    int yp = q / quads_per_row, xq = q - yp * quads_per_row;
+    if (q >= chunks_per_row * ph) return;
+    int yp = q / chunks_per_row, xc = q - yp * chunks_per_row;
     int img = blockIdx.y;
     int s = img / a.imgs_per_stream, cam = img - s * a.imgs_per_stream;
     const uint8_t* src = (cam == 0 ? a.img0 : a.img1) + s * a.img_stride;
     uint8_t* dst = pyr_of(a, img) + a.g.off[0];
     int y = av_reflect101(yp - AV_PYR_BORDER, h);
     const uint8_t* row = src + (size_t)y * w;
-    uint32_t out = 0;
+    const int x0 = xc * 16 - AV_PYR_BORDER;
+    uint4 out;
+    if (x0 >= 0 && x0 + 16 <= w && ((w | (int)(a.img_stride & 15) | (int)(reinterpret_cast<uintptr_t>(src) & 15)) & 15) == 0) {
+        out = *reinterpret_cast<const uint4*>(row + x0);
+    } else {
+        uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int xp = xq * 4 + i;
-        int x = av_reflect101(xp - AV_PYR_BORDER, w);
-        x = min(max(x, 0), w - 1);          // slack columns beyond w+32 (pitch rounding): any valid pixel
-        out |= (uint32_t)row[x] << (8 * i);
+        for (int i = 0; i < 16; ++i) {
+            int x = av_reflect101(x0 + i, w);
+            x = min(max(x, 0), w - 1);      // slack columns beyond w+32 (pitch rounding): any valid pixel
+            o[i >> 2] |= (uint32_t)row[x] << (8 * (i & 3));
+        }
+        out = make_uint4(o[0], o[1], o[2], o[3]);
     }
-    *reinterpret_cast<uint32_t*>(dst + (size_t)yp * pitch + xq * 4) = out;
+    *reinterpret_cast<uint4*>(dst + (size_t)yp * pitch + xc * 16) = out;
 }
 
 // level l (>= 1) from padded level l-1.
@@ -76,20 +83,42 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrArgs a, int level)
     // padded source rows 2y-2 .. 2y+2
     const uint8_t* r0 = src + (size_t)(2 * y - 2 + AV_PYR_BORDER) * spitch + AV_PYR_BORDER;
     uint32_t out = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int xp = xq * 4 + i;
-        int x = av_reflect101(xp - AV_PYR_BORDER, w);
-        x = min(max(x, 0), w - 1);
-        const uint8_t* p = r0 + 2 * x;
-        int hsum[5];
+    const int x0 = xq * 4 - AV_PYR_BORDER;
+    if (x0 >= 0 && x0 + 4 <= w) {
+        // interior quad: source bytes 2*x0-2 .. 2*x0+8 of each row sit inside the 16 bytes at 2*x0-4 (dword aligned:
+        // x0 is a multiple of 4, the padded pitch a multiple of 16).  Row filter [1 4 6 4] as one v_dot4 plus the fifth tap.
+        int hs[4][5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            const uint8_t* r = p + (size_t)k * spitch;
-            hsum[k] = (int)r[-2] + (int)r[2] + 4 * ((int)r[-1] + (int)r[1]) + 6 * (int)r[0];
+            const uint4 d = *reinterpret_cast<const uint4*>(r0 + (size_t)k * spitch + 2 * x0 - 4);
+            const uint32_t t0 = __builtin_amdgcn_alignbyte(d.y, d.x, 2), t1 = d.y, t2 = __builtin_amdgcn_alignbyte(d.z, d.y, 2), t3 = d.z;
+            const uint32_t W4 = 0x04060401u;
+            hs[0][k] = (int)__builtin_amdgcn_udot4(t0, W4, (d.y >> 16) & 0xFF, false);
+            hs[1][k] = (int)__builtin_amdgcn_udot4(t1, W4, d.z & 0xFF, false);
+            hs[2][k] = (int)__builtin_amdgcn_udot4(t2, W4, (d.z >> 16) & 0xFF, false);
+            hs[3][k] = (int)__builtin_amdgcn_udot4(t3, W4, d.w & 0xFF, false);
         }
-        int v = hsum[0] + hsum[4] + 4 * (hsum[1] + hsum[3]) + 6 * hsum[2];
-        out |= (uint32_t)((v + 128) >> 8) << (8 * i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = hs[i][0] + hs[i][4] + 4 * (hs[i][1] + hs[i][3]) + 6 * hs[i][2];
+            out |= (uint32_t)((v + 128) >> 8) << (8 * i);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int xp = xq * 4 + i;
+            int x = av_reflect101(xp - AV_PYR_BORDER, w);
+            x = min(max(x, 0), w - 1);
+            const uint8_t* p = r0 + 2 * x;
+            int hsum[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const uint8_t* r = p + (size_t)k * spitch;
+                hsum[k] = (int)r[-2] + (int)r[2] + 4 * ((int)r[-1] + (int)r[1]) + 6 * (int)r[0];
+            }
+            int v = hsum[0] + hsum[4] + 4 * (hsum[1] + hsum[3]) + 6 * hsum[2];
+            out |= (uint32_t)((v + 128) >> 8) << (8 * i);
+        }
     }
     *reinterpret_cast<uint32_t*>(dst + (size_t)yp * pitch + xq * 4) = out;
 }
@@ -118,8 +147,8 @@ int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stri
     a.slot0 = slot0; a.slot1 = slot1; a.g = g;
     const int n_img = n_streams * imgs_per_stream;
     {
-        int quads = (g.pitch[0] >> 2) * (g.h[0] + 2 * AV_PYR_BORDER);
-        dim3 grid((quads + 255) / 256, n_img);
+        int chunks = (g.pitch[0] >> 4) * (g.h[0] + 2 * AV_PYR_BORDER);
+        dim3 grid((chunks + 255) / 256, n_img);
         hipLaunchKernelGGL(pad_level0_kernel, grid, dim3(256), 0, st, a);
         AV_LAUNCH_CHECK();
     }
