@@ -27,12 +27,12 @@ sys.path.insert(0, ROOT)
 W_IMG, H_IMG = 752, 480
 LK_BYTES_PER_POINT_PASS = 4 * 2 * 289 + 25          # L=4 levels x (I + J window of 17x17) + point I/O
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/s spec
-# Memory-side traffic of lk_track_kernel per point pass, from rocprofv3 PMC passes of this same command
-# (profiles/r01/pmc_hbm_traffic_s64.json: FETCH_SIZE 112,948 KB and WRITE_SIZE 327 KB per launch of 19,200
-# point passes), corrected as MI355X_MICROARCH.md "HBM" prescribes for gfx950 (FETCH_SIZE x 2; WRITE_SIZE exact).
-# The x2 rule is calibrated for 16-B/lane streams; this kernel stages 32-byte row segments, so read it as an
-# upper bound (uncorrected: 6.0 KB per point pass).
-LK_TRAFFIC_BYTES_PER_POINT_PASS = (2 * 112948.17 + 326.98) * 1024 / 19200
+# Memory-side traffic of lk_track_g16_kernel per point pass, from rocprofv3 PMC passes of this same command
+# (profiles/r01/pmc_frontend_s64_lk_g16_summary.json: FETCH_SIZE 68,263 KB and WRITE_SIZE 295 KB per launch of 19,200
+# point passes at 64 streams), corrected as MI355X_MICROARCH.md "HBM" prescribes for gfx950 (FETCH_SIZE x 2;
+# WRITE_SIZE exact).  The x2 rule is calibrated for 16-B/lane streams; this kernel stages 32-byte row segments, so
+# read it as an upper bound (uncorrected: 3.7 KB per point pass against 2.3 KB algorithmic).
+LK_TRAFFIC_BYTES_PER_POINT_PASS = (2 * 68263.08 + 295.15) * 1024 / 19200
 
 
 def frame_bytes(n_t, n_trk, n_cand):
@@ -295,12 +295,14 @@ def main():
                 'frame_hbm_frac': fps / world * b_frame / 1e9 / HBM_PEAK_GBS,
             },
             'roofline': {
-                'bound': 'hbm', 'kernel': 'lk_track_kernel<15>',
+                'bound': 'hbm', 'kernel': 'lk_track_g16_kernel<15>',
                 'achieved': lk_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': lk_gbs / HBM_PEAK_GBS,
                 'traffic': LK_TRAFFIC_BYTES_PER_POINT_PASS * S * p_frame / 5.0,
-                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r01/pmc_hbm_traffic_s64.json, FETCH x2 per MI355X_MICROARCH.md',
-                'note': 'lk_track_kernel is VALU-issue bound (PMC: VALU busy ~100% at 4 cycles per wave64 instruction), '
-                        'its tiles come from L2/Infinity Cache; the HBM fraction is reported because the path class is byte/integer work',
+                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r01/pmc_frontend_s64_lk_g16_summary.json, FETCH x2 per MI355X_MICROARCH.md',
+                'note': 'lk_track_g16_kernel is VALU-issue bound (PMC: ~1,400 VALU instructions per point pass, 32% of wave cycles '
+                        'waiting on an instruction, LDS 2% of instructions); its tiles come from L2/Infinity Cache. The HBM fraction is '
+                        'reported because the path class is byte/integer work. In the complete path the span also contains the '
+                        'higher-priority filter kernels that preempt it.',
                 'avg_launch_ms': lk_avg_ms, 'launches': lk_n, 'algorithmic_bytes_per_launch': lk_bytes_per_launch,
             },
             'kernel_ms_per_step': {k: v[0] / K for k, v in timing.items()},
