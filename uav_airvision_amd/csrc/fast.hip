@@ -21,7 +21,7 @@
 
 namespace {
 
-constexpr int TW = 64, TH = 16;
+constexpr int TW = 64, TH = 48;
 constexpr int PW = TW + 8, PH = TH + 8;     // pixel tile
 constexpr int SW = TW + 2, SH = TH + 2;     // score tile
 constexpr int MAXLC = 16;                   // grid cells one tile may overlap
@@ -30,6 +30,7 @@ struct FastArgs {
     const uint8_t* img;
     int64_t img_stride;
     int img_pitch;
+    int border;                 // valid pixels around the w x h image in every direction (padded pyramid level: AV_PYR_BORDER; raw image: 0)
     const uint8_t* mask;
     int64_t mask_stride;
     int w, h, threshold;
@@ -67,7 +68,7 @@ __device__ __forceinline__ int fast_score(const uint8_t* c, int t)
 
 __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
 {
-    __shared__ uint8_t pix[PH * PW];
+    __shared__ __attribute__((aligned(16))) uint8_t pix[PH * PW];
     __shared__ uint8_t sc[SH * SW];
     __shared__ uint16_t cand[SH * SW];
     __shared__ int ncand;
@@ -77,10 +78,23 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
     const int tid = threadIdx.x;
 
     if (tid == 0) ncand = 0;
-    for (int i = tid; i < PH * PW; i += 256) {
-        int r = i / PW, c = i - r * PW;
-        int y = min(max(y0 - 4 + r, 0), a.h - 1), x = min(max(x0 - 4 + c, 0), a.w - 1);
-        pix[i] = img[(size_t)y * a.img_pitch + x];
+    // pixel tile: 24 rows x 72 bytes from (x0-4, y0-4).  Tiles whose footprint lies inside the (padded) image copy dwords
+    // (x0 is a multiple of 64, so x0-4 is dword aligned when pitch and base are); the others clamp per byte.  Pixels
+    // outside the image never reach a valid output (corners need x, y in [3, dim-3)), so clamp vs reflect is immaterial.
+    const bool inside = x0 - 4 >= -a.border && x0 - 4 + PW <= a.w + a.border && y0 - 4 >= -a.border && y0 - 4 + PH <= a.h + a.border &&
+                        ((a.img_pitch | (int)(a.img_stride & 3) | (int)(reinterpret_cast<uintptr_t>(a.img) & 3)) & 3) == 0;
+    if (inside) {
+        uint32_t* pixw = reinterpret_cast<uint32_t*>(pix);
+        for (int i = tid; i < PH * (PW / 4); i += 256) {
+            const int r = i / (PW / 4), c = i - r * (PW / 4);
+            pixw[i] = *reinterpret_cast<const uint32_t*>(img + (ptrdiff_t)(y0 - 4 + r) * a.img_pitch + (x0 - 4) + 4 * c);
+        }
+    } else {
+        for (int i = tid; i < PH * PW; i += 256) {
+            int r = i / PW, c = i - r * PW;
+            int y = min(max(y0 - 4 + r, 0), a.h - 1), x = min(max(x0 - 4 + c, 0), a.w - 1);
+            pix[i] = img[(size_t)y * a.img_pitch + x];
+        }
     }
     __syncthreads();
     // Phase 1: cheap necessary condition on the 4 compass pixels of the ring (any 9-arc contains at
@@ -120,8 +134,8 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
     // Phase 3: 3x3 non-max suppression + mask; survivors go to an LDS list first so that the tile issues
     // ONE returning global atomic per output list it touches (a 64x16 tile overlaps <= 4 grid cells)
     // instead of one per keypoint.
-    __shared__ uint32_t surv_word[256];
-    __shared__ int surv_cell[256];
+    __shared__ uint32_t surv_word[TW * TH / 4];             // strict 3x3 maxima: at most one per 2x2 block
+    __shared__ int surv_cell[TW * TH / 4];
     __shared__ int nsurv, cell_base[MAXLC], flat_base;
     if (tid == 0) nsurv = 0;
     __syncthreads();
@@ -141,7 +155,7 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
                     s > p[SW - 1] && s > p[SW] && s > p[SW + 1];
         if (keep && a.mask) keep = a.mask[img_i * a.mask_stride + (size_t)y * a.w + x] != 0;
         if (keep) {
-            const int slot = atomicAdd(&nsurv, 1);            // LDS atomic; a tile has <= 256 strict maxima
+            const int slot = atomicAdd(&nsurv, 1);            // LDS atomic; a tile has <= TW*TH/4 strict maxima
             surv_word[slot] = ((uint32_t)s << AV_KP_RASTER_BITS) | (AV_KP_RASTER_MASK - (uint32_t)(y * a.w + x));
             surv_cell[slot] = a.cell_kp ? ((y / a.gh - cy0) * ncx + (x / a.gw - cx0)) : 0;      // tile-local cell index
         }
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
 
 }  // namespace
 
-int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, const uint8_t* mask, int64_t mask_stride,
+int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, int border, const uint8_t* mask, int64_t mask_stride,
                    int n_img, int w, int h, int threshold,
                    uint32_t* kp, int* count, int cap,
                    uint32_t* cell_kp, int* cell_count, int cell_cap, int gh, int gw, int grid_col, int n_cells,
@@ -201,7 +215,7 @@ int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, const 
         return AV_E_INVALID;
     }
     FastArgs a;
-    a.img = img; a.img_stride = img_stride; a.img_pitch = img_pitch; a.mask = mask; a.mask_stride = mask_stride;
+    a.img = img; a.img_stride = img_stride; a.img_pitch = img_pitch; a.border = border; a.mask = mask; a.mask_stride = mask_stride;
     a.w = w; a.h = h; a.threshold = threshold;
     a.kp = kp; a.count = count; a.cap = cap;
     a.cell_kp = cell_kp; a.cell_count = cell_count; a.cell_cap = cell_cap; a.gh = gh; a.gw = gw;
@@ -222,6 +236,6 @@ AV_EXPORT int av_fast_detect(const uint8_t* img_dev, int64_t img_stride, const u
     }
     hipStream_t st = (hipStream_t)stream;
     AV_HIP(hipMemsetAsync(count_dev, 0, sizeof(int) * (size_t)n_img, st));
-    return av_launch_fast(img_dev, img_stride, w, mask_dev, mask_stride, n_img, w, h, threshold, kp_dev, count_dev, cap,
+    return av_launch_fast(img_dev, img_stride, w, 0, mask_dev, mask_stride, n_img, w, h, threshold, kp_dev, count_dev, cap,
                           nullptr, nullptr, 0, 1, 1, 1, 1, nullptr, nullptr, 0, st);
 }

@@ -634,7 +634,10 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
       hipLaunchKernelGGL(rebin_kernel, dim3(S), dim3(256), 0, st, d, par);
       AV_LAUNCH_CHECK(); }
     Span* fast_span = new Span(fe, 2, st);
-    if ((rc = av_launch_fast(img0, img_stride, d.w, d.mask, (int64_t)d.w * d.h, S, d.w, d.h, fe->cfg.fast_threshold,
+    // FAST reads level 0 of the cam0 pyramid built above (same pixels as the input image, with a 16-pixel frame: every
+    // tile but the right-most column copies whole dwords without clamping)
+    const uint8_t* fast_img = P_cur0 + fe->geom.off[0] + (size_t)AV_PYR_BORDER * fe->geom.pitch[0] + AV_PYR_BORDER;
+    if ((rc = av_launch_fast(fast_img, sstride, fe->geom.pitch[0], AV_PYR_BORDER, d.mask, (int64_t)d.w * d.h, S, d.w, d.h, fe->cfg.fast_threshold,
                              nullptr, nullptr, 0, d.cell_kp, d.cell_count, d.cell_cap, d.gh, d.gw, d.grid_col, d.C,
                              d.counters + CNT_FAST, d.counters + CNT_OVF, NCNT, st))) { delete fast_span; return rc; }
     delete fast_span;
