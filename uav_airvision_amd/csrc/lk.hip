@@ -453,6 +453,7 @@ __global__ __launch_bounds__(256) void lk_track_g16_kernel(LKArgs a)
             // the derivative image is zero outside the image: only windows at the border pay for the masks
             const bool inside = ipx >= 0 && ipx + WIN < w && ipy >= 0 && ipy + WIN < h;
             if (__builtin_amdgcn_ballot_w64(!inside) != 0) {
+                __builtin_amdgcn_s_sleep(0);        // a side effect keeps the compiler from if-converting this (rare) block into selects on the common path
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
                     const bool rowin = (unsigned)(ipy + rr + dy) < (unsigned)h;
