@@ -284,6 +284,7 @@ struct FeatArgs {
     const int* feat_list;                // optional: team t processes feature feat_list[t] (launch buckets by track length)
     int n_list;                          // teams to run in this launch
     int team_doubles;                    // LDS doubles per team (wavefront teams: four per workgroup)
+    unsigned long long* prof;            // optional [8] phase stamps of team 0 (diagnostic runs, AV_MSCKF_TIMING)
 };
 
 // dynamic LDS of feature_kernel for tracks of at most Mx observations (layout at the top of the kernel)
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
     for (int i = tid; i < R4 * C6; i += TEAM) H[i] = 0.0;
     for (int i = tid; i < M; i += TEAM) cidx[i] = a.obs_cam[o0 + i];
     team_sync<TEAM>();
+    if (a.prof && slot == 0 && tid == 0) a.prof[0] = __builtin_amdgcn_s_memrealtime();
 
     // ---- measurement_jacobian per observation (msckf.py:443-507): thread j < M ---------------------
     if (tid < M) {
@@ -408,6 +410,7 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
     }
     team_sync<TEAM>();
 
+    if (a.prof && slot == 0 && tid == 0) a.prof[1] = __builtin_amdgcn_s_memrealtime();
     // ---- G = H_x Psub H_x^T (R4 x R4).  Before the projection H_x is block diagonal (one 4x6 block per observation),
     //      so G is M x M blocks  Hj P[cam j][cam l] Hl^T: one thread per block pair reads its 6x6 block of P once.  The gate
     //      matrix A^T H_x Psub H_x^T A (msckf.py:604-612 on the projected Jacobian) is then the trailing K x K block of
@@ -446,6 +449,7 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
     }
     team_sync<TEAM>();
 
+    if (a.prof && slot == 0 && tid == 0) a.prof[2] = __builtin_amdgcn_s_memrealtime();
     // ---- left null space of H_f by 3 Householder reflectors, applied to H and r (msckf.py:540-544) --
     for (int k = 0; k < 3; ++k) {
         // norm of Hf[k:, k]
@@ -469,22 +473,28 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
         // columns to transform: all C6 columns of H, the remaining Hf columns (k+1..2), r, and the R4 columns of G
         auto reflect = [&](double* col, int stride) {
             double dot = v0 * col[k * stride];
-            for (int i = k + 1; i < R4; ++i) dot += Hf[i * 3 + k] * col[i * stride];
+#pragma unroll 8
+            for (int i = k + 1; i < R4; ++i) dot += Hf[i * 3 + k] * col[i * stride];        // unrolled: the LDS loads of 8 rows are in flight together
             dot *= tau;
             col[k * stride] -= dot * v0;
+#pragma unroll 8
             for (int i = k + 1; i < R4; ++i) col[i * stride] -= dot * Hf[i * 3 + k];
         };
         const int nfix = C6 + (2 - k) + 1, njobs = nfix + R4;
         for (int job = tid; job < njobs; job += TEAM) {
-            if (job < C6) reflect(H + job, C6);
-            else if (job < C6 + (2 - k)) reflect(Hf + (k + 1 + job - C6), 3);
-            else if (job < nfix) reflect(rr, 1);
-            else reflect(S + (job - nfix), SP);
+            // one call site: the lanes of a wavefront differ only in (column, stride), not in control flow
+            double* col; int stride;
+            if (job < C6) { col = H + job; stride = C6; }
+            else if (job < C6 + (2 - k)) { col = Hf + (k + 1 + job - C6); stride = 3; }
+            else if (job < nfix) { col = rr; stride = 1; }
+            else { col = S + (job - nfix); stride = SP; }
+            reflect(col, stride);
         }
         team_sync<TEAM>();
         for (int job = tid; job < R4; job += TEAM) reflect(S + job * SP, 1);       // ... and G from the right
         team_sync<TEAM>();
     }
+    if (a.prof && slot == 0 && tid == 0) a.prof[3] = __builtin_amdgcn_s_memrealtime();
     // rows 3..R4-1 of H and r are A^T H_x and A^T r.  Write them out (dense row of width ld).
     const int row0 = a.row_off[f];
     for (int i = tid; i < K * a.ld; i += TEAM) {
@@ -498,35 +508,36 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
     }
     for (int i = tid; i < K; i += TEAM) rout[row0 + i] = rr[3 + i];
 
+    if (a.prof && slot == 0 && tid == 0) a.prof[4] = __builtin_amdgcn_s_memrealtime();
     // ---- gating test (msckf.py:604-612): S = H' Psub H'^T + s^2 I = (Q^T G Q)[3:, 3:] + s^2 I, gamma = r'^T S^-1 r' ----
     double* Sg = S + 3 * SP + 3;                 // K x K, row pitch SP
     for (int i = tid; i < K; i += TEAM) Sg[i * SP + i] += a.obs_noise;
     team_sync<TEAM>();
-    // Cholesky S = L L^T (lower, in place) and forward solve L y = r'
+    // gamma = r'^T S^-1 r' by a right-looking LDL^T that carries r' along as one more row: at step j the pivot d_j and
+    // w_j = (L^-1 r')_j * sqrt(d_j) are final, gamma += w_j^2 / d_j, and the trailing block and the rest of w get their
+    // rank-1 update.  One barrier per column, no square roots, no separate substitution pass (the single-thread forward
+    // solve used to be half of this kernel's time on long tracks).
+    double* wv = rr + 3;
+    constexpr int GX = TEAM == 256 ? 16 : 8, GY = TEAM / GX;
+    const int tx = tid % GX, ty = tid / GX;
+    double g = 0;
     for (int k = 0; k < K; ++k) {
-        if (tid == 0) Sg[k * SP + k] = sqrt(Sg[k * SP + k]);
-        team_sync<TEAM>();
-        const double dkk = Sg[k * SP + k];
-        for (int i = k + 1 + tid; i < K; i += TEAM) Sg[i * SP + k] /= dkk;
-        team_sync<TEAM>();
-        const int rem = K - k - 1;
-        for (int e = tid; e < rem * rem; e += TEAM) {
-            const int i = k + 1 + e / rem, jj = k + 1 + e % rem;
-            if (jj <= i) Sg[i * SP + jj] -= Sg[i * SP + k] * Sg[jj * SP + k];
+        const double inv = 1.0 / Sg[k * SP + k];
+        const double wk = wv[k], zk = wk * inv;
+        g += wk * zk;
+        for (int i = k + 1 + ty; i < K; i += GY) {
+            const double aik = Sg[i * SP + k];
+            const double lik = aik * inv;
+#pragma unroll 4
+            for (int jj = k + 1 + tx; jj <= i; jj += GX) Sg[i * SP + jj] -= lik * Sg[jj * SP + k];
+            if (tx == 0) wv[i] -= aik * zk;
         }
         team_sync<TEAM>();
     }
     if (tid == 0) {
-        double g = 0;
-        for (int i = 0; i < K; ++i) {
-            double v = rr[3 + i];
-            for (int jj = 0; jj < i; ++jj) v -= Sg[i * SP + jj] * red[jj];
-            v /= Sg[i * SP + i];
-            red[i] = v;                          // K <= 77 < 256
-            g += v * v;
-        }
         a.gamma[f] = g;
         a.pass[f] = g < a.chi2[a.dof[f]] ? 1 : 0;
+        if (a.prof && slot == 0) a.prof[5] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -1479,7 +1490,7 @@ AV_EXPORT int av_msckf_feature_blocks(av_msckf* c, int n_feat, int n_cam, int ma
     for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) a.R01[r * 3 + cc] = T_cam0_cam1_rowmajor44[r * 4 + cc]; a.t01[r] = T_cam0_cam1_rowmajor44[r * 4 + 3]; a.gravity[r] = gravity[r]; }
     a.obs_noise = obs_noise; a.Hout = c->Hblk; a.rout = c->rblk; a.gamma = gamma_dev; a.pass = pass_dev; a.Mmax = max_obs;
     a.feat_stream = nullptr; a.stream_ncam = nullptr; a.stream_gravity = nullptr; a.cam_stride = 0; a.p_stride = a.h_stride = a.r_stride = 0;
-    a.feat_list = nullptr;
+    a.feat_list = nullptr; a.prof = nullptr;
     AV_HIP(hipSetDevice(c->device));
     return launch_feature_kernel(a, n_feat, max_obs, (hipStream_t)stream);
 }
