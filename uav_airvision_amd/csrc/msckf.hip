@@ -69,6 +69,15 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     v += dpp_f64<0x140>(v);      // row_mirror
     return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
 }
+// sum over the 16 lanes of a DPP row, returned to each of them (teams of 16 lanes: four independent sums per wavefront)
+__device__ __forceinline__ double row16_sum_f64(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return v;
+}
 
 // ================================================================================================
 // Triangulation: one wavefront per feature, lane = view (obs j, camera c) with view = 2j + c.
@@ -288,9 +297,10 @@ struct FeatArgs {
 };
 
 // dynamic LDS of feature_kernel for tracks of at most Mx observations (layout at the top of the kernel)
-static inline size_t feature_lds_bytes(int Mx)
+static inline size_t feature_lds_bytes(int Mx, int team = 256)
 {
-    return sizeof(double) * ((size_t)(4 * Mx) * (6 * Mx) + (4 * Mx) * 3 + 4 * Mx + (size_t)(4 * Mx) * (4 * Mx + 1) + 256) + sizeof(int) * Mx + 16;
+    const size_t red = team == 256 ? 256 : 0;           // tree-reduction scratch of the workgroup teams only
+    return sizeof(double) * ((size_t)(4 * Mx) * (6 * Mx) + (4 * Mx) * 3 + 4 * Mx + (size_t)(4 * Mx) * (4 * Mx + 1) + red) + sizeof(int) * Mx + 16;
 }
 
 // TEAM = threads that cooperate on one feature: a whole 256-thread workgroup for long tracks, one wavefront (four
@@ -306,7 +316,7 @@ __device__ __forceinline__ void team_sync()
 }
 
 template <int TEAM>
-__global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
+__device__ __forceinline__ void feature_body(const FeatArgs& a)
 {
     extern __shared__ double sm_all[];
     const int slot = TEAM == 256 ? (int)blockIdx.x : (int)(blockIdx.x * (256 / TEAM) + threadIdx.x / TEAM);
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
     double* S = rr + 4 * Mx;                     // [4Mx][4Mx+1]  (odd row pitch: row-wise reflector jobs stay off the same banks)
     double* red = S + (4 * Mx) * (4 * Mx + 1);   // [256] reduction scratch
     const int SP = R4 + 1;
-    int* cidx = reinterpret_cast<int*>(red + 256);   // [Mx] camera index per observation
+    int* cidx = reinterpret_cast<int*>(red + (TEAM == 256 ? 256 : 0));   // [Mx] camera index per observation
 
     for (int i = tid; i < R4 * C6; i += TEAM) H[i] = 0.0;
     for (int i = tid; i < M; i += TEAM) cidx[i] = a.obs_cam[o0 + i];
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
             nrm = sqrt(red[0]);
             team_sync<TEAM>();
         } else {
-            nrm = sqrt(wave_sum_f64(part));
+            nrm = sqrt(TEAM == 64 ? wave_sum_f64(part) : row16_sum_f64(part));
         }
         const double akk = Hf[k * 3 + k];
         const double alpha = akk >= 0 ? -nrm : nrm;
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
     // rank-1 update.  One barrier per column, no square roots, no separate substitution pass (the single-thread forward
     // solve used to be half of this kernel's time on long tracks).
     double* wv = rr + 3;
-    constexpr int GX = TEAM == 256 ? 16 : 8, GY = TEAM / GX;
+    constexpr int GX = TEAM == 256 ? 16 : (TEAM == 64 ? 8 : 4), GY = TEAM / GX;
     const int tx = tid % GX, ty = tid / GX;
     double g = 0;
     for (int k = 0; k < K; ++k) {
@@ -541,6 +551,14 @@ __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a)
     }
 }
 
+// Long tracks: one workgroup per feature.  Short tracks: one wavefront per feature; those are latency-bound chains of
+// small fp64 steps, so the register budget is capped for 8 waves per SIMD (the Jacobian phase spills, but only its two
+// active lanes touch scratch) -- twice the features in flight per CU.
+template <int TEAM> __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a);
+template <> __global__ __launch_bounds__(256) void feature_kernel<256>(FeatArgs a) { feature_body<256>(a); }
+template <> __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(256) void feature_kernel<64>(FeatArgs a) { feature_body<64>(a); }
+template <> __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(256) void feature_kernel<16>(FeatArgs a) { feature_body<16>(a); }
+
 static int msckf_lds_opt_in();       // raises the dynamic-LDS limit of every kernel below once per process
 
 // Launch `cnt` features (a.feat_list or 0..cnt-1) whose tracks hold at most Mx observations.
@@ -549,15 +567,16 @@ static int launch_feature_kernel(FeatArgs a, int cnt, int Mx, hipStream_t st)
     int rc0 = msckf_lds_opt_in();
     if (rc0) return rc0;
     a.Mmax = Mx; a.n_list = cnt;
-    const size_t per = (feature_lds_bytes(Mx) + 7) / 8 * 8;
+    // team size: 16 lanes (one DPP row, 16 features per workgroup) for the two-observation features of the prune path,
+    // one wavefront up to 4 observations, one workgroup beyond.  (env: A/B and debugging aid, forces workgroup teams)
+    const int team = getenv("AV_FEATURE_BLOCK_TEAMS") ? 256 : (Mx <= 2 ? 16 : (Mx <= 4 ? 64 : 256));
+    const size_t per = (feature_lds_bytes(Mx, team) + 7) / 8 * 8;
     a.team_doubles = (int)(per / 8);
-    if (per > 160 * 1024) { av_set_error("MSCKF feature blocks: %d observations per feature need %zu B of LDS", Mx, per); return AV_E_CAPACITY; }
-    if (Mx <= 4 && !getenv("AV_FEATURE_BLOCK_TEAMS")) {        // (env: A/B and debugging aid, forces one workgroup per feature)
-        const size_t lds = per * 4;
-        hipLaunchKernelGGL(feature_kernel<64>, dim3((cnt + 3) / 4), dim3(256), lds, st, a);
-    } else {
-        hipLaunchKernelGGL(feature_kernel<256>, dim3(cnt), dim3(256), per, st, a);
-    }
+    const size_t lds = per * (256 / team);
+    if (lds > 160 * 1024) { av_set_error("MSCKF feature blocks: %d observations per feature need %zu B of LDS", Mx, lds); return AV_E_CAPACITY; }
+    if (team == 16) hipLaunchKernelGGL(feature_kernel<16>, dim3((cnt + 15) / 16), dim3(256), lds, st, a);
+    else if (team == 64) hipLaunchKernelGGL(feature_kernel<64>, dim3((cnt + 3) / 4), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(feature_kernel<256>, dim3(cnt), dim3(256), lds, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
@@ -1292,7 +1311,7 @@ static int msckf_lds_opt_in()
 {
     static const int rc = [] {
         const int lim = 160 * 1024;
-        const void* fns[4] = {reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
+        const void* fns[5] = {reinterpret_cast<const void*>(feature_kernel<16>), reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
                               reinterpret_cast<const void*>(update_front_kernel), reinterpret_cast<const void*>(update_front_batch_kernel)};
         const void* fns2[2] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel)};
         for (const void* f : fns2) {
