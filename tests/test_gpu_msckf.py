@@ -240,3 +240,47 @@ def test_batched_filter_inactive_stream_and_online_reset():
     for i in range(2):
         assert np.abs(bat.get_cov(i) - oras[i].state_cov).max() <= 1e-6 * max(1e-3, np.abs(oras[i].state_cov).max())
     bat.close()
+
+
+def test_batched_filter_1500_features_per_frame(cfg):
+    """BASELINE configs[4] shape: 1500 features per frame.  The two-camera prune then stacks ~7000 rows per stream
+    (beyond the register-resident QR shapes: the global-memory fallback runs) and the lost-feature path hits the
+    `> 1500 rows` cut of msckf.py:667-668.  Compared with the numpy oracle frame by frame."""
+    from oracle.msckf_np import OracleMSCKF
+    from uav_airvision_amd.msckf_ops import BatchedMSCKF
+    from uav_airvision_amd.synth import SyntheticFeatureStream
+    n_frames = 24
+    st = SyntheticFeatureStream(cfg, seed=41, n_frames=n_frames, n_features=1500)
+    bat = BatchedMSCKF(cfg, 1, rows_cap=8192)
+    ora = OracleMSCKF(cfg)
+    it = iter(st.imu); pend = next(it, None)
+    cap = 1536
+    pruned = False
+    for k in range(n_frames):
+        m = st.frame(k)
+        si, ts, gy, ac = [], [], [], []
+        while pend is not None and pend.timestamp <= m.timestamp:
+            ora.imu_callback(pend)
+            si.append(0); ts.append(pend.timestamp); gy.append(pend.angular_velocity); ac.append(pend.linear_acceleration)
+            pend = next(it, None)
+        if si:
+            bat.push_imu(si, ts, gy, ac)
+        ids = np.zeros((1, cap), np.int64); uv = np.zeros((1, cap, 4)); nf = np.array([len(m.features)], np.int32)
+        for j, f in enumerate(m.features):
+            ids[0, j] = f.id; uv[0, j] = (f.u0, f.v0, f.u1, f.v1)
+        ncam_before = len(ora.cam_states)
+        out = bat.step(ids, uv, nf, [m.timestamp])
+        r = ora.feature_callback(m)
+        assert (r is not None) == bool(out[0, 0])
+        if r is None:
+            continue
+        pruned = pruned or len(ora.cam_states) < ncam_before
+        n, ncam, nmap = bat.sizes(0)
+        assert (n, ncam, nmap) == (ora.state_cov.shape[0], len(ora.cam_states), len(ora.map_server)), k
+        s = ora.imu_state
+        err = max(np.abs(out[0, 2:5] - s.position).max(), np.abs(out[0, 5:9] - s.orientation).max(), np.abs(out[0, 9:12] - s.velocity).max())
+        assert err < 1e-6, (k, err)
+    assert pruned, 'the run must reach the camera-state pruning path'
+    P, Po = bat.get_cov(0), ora.state_cov
+    assert np.abs(P - Po).max() <= 1e-6 * np.abs(Po).max()
+    bat.close()
