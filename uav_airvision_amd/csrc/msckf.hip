@@ -866,7 +866,7 @@ struct UpdArgs {
     double* W;                                   // [ld+1][ldt] TRANSPOSED work copy of [H | r] (column c at W + c*ldt)
     int ldt;                                     // leading dimension of W (>= m)
     const int* cols; int nc;                     // the non-zero columns of the stacked Jacobian (ascending), device pointer
-    unsigned long long* prof;                    // optional [8] phase timestamps (100 MHz ticks), diagnostic builds/runs only
+    unsigned long long* prof;                    // optional [16] phase timestamps (100 MHz ticks), diagnostic builds/runs only
     double* T;                                   // [k][ld]
     double* Kt;                                  // [k][ld]
     double* Pn;                                  // [n][ld]
@@ -1130,6 +1130,84 @@ __device__ __forceinline__ void update_front(const UpdArgs& a)
     stamp(2);
 }
 
+
+// C[r][c] = sum_q A(q, r) * B(q, c)  for r < R, c < Cn, q < Q, by one 1024-thread workgroup: 4x4 register tiles (at most
+// two per thread), operands staged through LDS in panels of 16 values of q (wavefront w stages panel row w, lanes along
+// the row: coalesced).  The unstaged form re-reads every operand value from L2 once per tile that needs it and is bound
+// by the one CU's vector-memory path (64 B/clk); staged, global traffic drops from O(tiles * Q) to O((R + Cn) * Q).
+constexpr int PANEL_Q = 16, PANEL_W = 208;      // PANEL_W >= 4 * ceil(max(R, Cn) / 4): n <= 21 + 6 * 31 = 207 (and <= 256 = 4 values per lane)
+template <typename FA, typename FB, typename FOUT>
+__device__ __forceinline__ void panel_gemm(int R, int Cn, int Q, double* pa, double* pb, bool lower_only, FA loadA, FB loadB, FOUT out)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tr = (R + 3) >> 2, tc = (Cn + 3) >> 2;
+    const int RA = tr * 4, CB = tc * 4;
+    for (int tbase = 0; tbase < tr * tc; tbase += 2 * UT) {              // one pass for n <= 181 (2048 tiles)
+        int r0[2], c0[2]; bool act[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = tbase + tid + u * UT;
+            act[u] = t < tr * tc;
+            r0[u] = act[u] ? (t / tc) * 4 : 0; c0[u] = act[u] ? (t % tc) * 4 : 0;
+            if (lower_only && c0[u] > r0[u] + 3) act[u] = false;        // tile entirely above the diagonal
+        }
+        double acc[2][4][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[u][i][j] = 0.0;
+        // software pipeline: the next panel's global loads are issued into registers before the current panel is consumed
+        double ra[4], rb[4];
+        auto fetch = [&](int q0) {
+            const int qn = min(PANEL_Q, Q - q0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = lane + 64 * i;
+                ra[i] = (wave < qn && e < R) ? loadA(q0 + wave, e) : 0.0;
+                rb[i] = (wave < qn && e < Cn) ? loadB(q0 + wave, e) : 0.0;
+            }
+        };
+        fetch(0);
+        for (int q0 = 0; q0 < Q; q0 += PANEL_Q) {
+            const int qn = min(PANEL_Q, Q - q0);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = lane + 64 * i;
+                if (e < RA) pa[wave * PANEL_W + e] = ra[i];
+                if (e < CB) pb[wave * PANEL_W + e] = rb[i];
+            }
+            __syncthreads();
+            if (q0 + PANEL_Q < Q) fetch(q0 + PANEL_Q);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!act[u]) continue;
+                const double* ap = pa + r0[u];
+                const double* bp = pb + c0[u];
+#pragma unroll 4
+                for (int q = 0; q < qn; ++q) {
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { av[i] = ap[q * PANEL_W + i]; bv[i] = bp[q * PANEL_W + i]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[u][i][j] += av[i] * bv[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!act[u]) continue;
+            out(r0[u], c0[u], acc[u]);                 // the tile's owner writes it (rows/columns beyond R / Cn are the functor's to skip)
+        }
+        __syncthreads();
+    }
+}
+typedef double av_d4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ void update_back(const UpdArgs& a)
 {
     extern __shared__ double Lp[];               // packed lower triangle of S / its Cholesky factor: k(k+1)/2
@@ -1140,61 +1218,31 @@ __device__ __forceinline__ void update_back(const UpdArgs& a)
     double* Wt = a.W;
     double* rcol = Wt + (size_t)nc * ldt;
     const int k = m > nc ? nc : m;
-    // 3. T = H_thin P  (k x n):  T[r][c] = sum_q Wt[q][r] P[cols[q]][c].  Register-tiled: each thread owns a 4x4
-    //    micro-tile, per q it loads 4 contiguous values of each operand (32 B) and does 16 FMAs.
-    {
-        const int tr = (k + 3) >> 2, tc = (n + 3) >> 2;
-        for (int t = tid; t < tr * tc; t += UT) {
-            const int r0 = (t / tc) * 4, c0 = (t % tc) * 4;
-            double acc[4][4] = {{0}};
-#pragma unroll 4
-            for (int q = 0; q < nc; ++q) {
-                const double* ap = Wt + (size_t)q * ldt + r0;                 // rows r0..r0+3 of column q (ldt >= m >= k; reads past k stay inside the column)
-                const double* bp = a.P + (size_t)a.cols[q] * a.ld + c0;       // ld is padded to a multiple of 8 >= n
-                double av[4], bv[4];
+    // 3. T = H_thin P (k x n): T[r][c] = sum_q Wt[q][r] P[cols[q]][c];  4. S = T H_thin^T + s^2 I (packed lower triangle in
+    //    LDS): S[r][c] = sum_q T[r][cols[q]] Wt[q][c].  Both through panel_gemm (LDS-staged operands, 4x4 register tiles).
+    double* pa = Lp + (size_t)k * (k + 1) / 2 + 8;
+    double* pb = pa + PANEL_Q * PANEL_W;
+    panel_gemm(k, n, nc, pa, pb, false,
+               [&](int q, int r) { return Wt[(size_t)q * ldt + r]; },
+               [&](int q, int c) { return a.P[(size_t)a.cols[q] * a.ld + c]; },
+               [&](int r0, int c0, const double (&t)[4][4]) {
+                   // rows of 4 doubles (32 B aligned: ld is a multiple of 8, c0 of 4); columns n..ld-1 of T are padding
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { av[u] = ap[u]; bv[u] = bp[u]; }
+                   for (int i = 0; i < 4; ++i) if (r0 + i < k) { av_d4 o = {t[i][0], t[i][1], t[i][2], t[i][3]}; *reinterpret_cast<av_d4*>(a.T + (size_t)(r0 + i) * a.ld + c0) = o; }
+               });
+    stamp(8);
+    panel_gemm(k, k, nc, pa, pb, true,
+               [&](int q, int r) { return a.T[(size_t)r * a.ld + a.cols[q]]; },
+               [&](int q, int c) { return Wt[(size_t)q * ldt + c]; },
+               [&](int r0, int c0, const double (&t)[4][4]) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                   for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) if (r0 + u < k && c0 + v < n) a.T[(size_t)(r0 + u) * a.ld + c0 + v] = acc[u][v];
-        }
-    }
-    __syncthreads();
-    // 4. S = T H_thin^T + s^2 I, packed lower triangle in LDS:  S[r][c] = sum_q T[r][cols[q]] Wt[q][c]   (4x4 tiles, lower part kept)
-    {
-        const int tk = (k + 3) >> 2;
-        for (int t = tid; t < tk * tk; t += UT) {
-            const int r0 = (t / tk) * 4, c0 = (t % tk) * 4;
-            if (c0 > r0 + 3) continue;                                        // tile entirely above the diagonal
-            double acc[4][4] = {{0}};
-#pragma unroll 4
-            for (int q = 0; q < nc; ++q) {
-                const int cq = a.cols[q];
-                const double* bp = Wt + (size_t)q * ldt + c0;
-                double av[4], bv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { av[u] = r0 + u < k ? a.T[(size_t)(r0 + u) * a.ld + cq] : 0.0; bv[u] = bp[u]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int r = r0 + u, c = c0 + v;
-                    if (r < k && c <= r) Lp[(size_t)r * (r + 1) / 2 + c] = acc[u][v] + (r == c ? a.obs_noise : 0.0);
-                }
-        }
-    }
-    __syncthreads();
+                       for (int j = 0; j < 4; ++j) {
+                           const int r = r0 + i, c = c0 + j;
+                           if (r < k && c <= r) Lp[(size_t)r * (r + 1) / 2 + c] = t[i][j] + (r == c ? a.obs_noise : 0.0);
+                       }
+               });
     stamp(3);
     // 5. Cholesky in LDS, right-looking with the column scaling deferred: step j only subtracts a_rj a_cj / d_j from the
     //    trailing block (one barrier per column instead of three); columns are divided by sqrt(d_j) in one pass at the end.
@@ -1257,34 +1305,46 @@ __device__ __forceinline__ void update_back(const UpdArgs& a)
         for (int i = 0; i < k; ++i) s += a.Kt[(size_t)i * a.ld + c] * rcol[i];
         a.dx[c] = s;
     }
-    // 8. P <- sym(P - Y^T Y): 4x4 register tiles over the full n x n (Y^T Y is symmetric, so the result already is)
-    {
-        const int tn = (n + 3) >> 2;
-        for (int t = tid; t < tn * tn; t += UT) {
-            const int r0 = (t / tn) * 4, c0 = (t % tn) * 4;
-            double acc[4][4] = {{0}};
-#pragma unroll 4
-            for (int q = 0; q < k; ++q) {
-                const double* yr = a.Kt + (size_t)q * a.ld + r0;
-                const double* yc = a.Kt + (size_t)q * a.ld + c0;
-                double av[4], bv[4];
+    stamp(9);
+    // 8. P <- sym(P - Y^T Y) (msckf.py:597-602).  The (r,c) and (c,r) elements of Y^T Y are the same products summed in
+    //    the same order, so both halves of the symmetrisation are available to the tile that owns (r,c): it reads the
+    //    4x4 tile of P and its mirror tile (both row segments of 32 B), and the transposed, uncoalesced pass over the
+    //    whole matrix that the separate (P + P^T)/2 needed is gone.  Pn then holds the result; a coalesced copy moves it back.
+    panel_gemm(n, n, k, pa, pb, false,
+               [&](int q, int r) { return a.Kt[(size_t)q * a.ld + r]; },
+               [&](int q, int c) { return a.Kt[(size_t)q * a.ld + c]; },
+               [&](int r0, int c0, const double (&t)[4][4]) {
+                   if (r0 + 3 < n && c0 + 3 < n) {
+                       av_d4 prow[4], mrow[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { av[u] = yr[u]; bv[u] = yc[u]; }
+                       for (int i = 0; i < 4; ++i) {
+                           prow[i] = *reinterpret_cast<const av_d4*>(a.P + (size_t)(r0 + i) * a.ld + c0);
+                           mrow[i] = *reinterpret_cast<const av_d4*>(a.P + (size_t)(c0 + i) * a.ld + r0);
+                       }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                       for (int i = 0; i < 4; ++i) {
+                           av_d4 o;
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
-            }
+                           for (int j = 0; j < 4; ++j) o[j] = ((prow[i][j] - t[i][j]) + (mrow[j][i] - t[i][j])) / 2.;
+                           *reinterpret_cast<av_d4*>(a.Pn + (size_t)(r0 + i) * a.ld + c0) = o;
+                       }
+                   } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+                       for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) if (r0 + u < n && c0 + v < n) a.Pn[(size_t)(r0 + u) * a.ld + c0 + v] = a.P[(size_t)(r0 + u) * a.ld + c0 + v] - acc[u][v];
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < n * n; i += UT) {
-        int r = i / n, c = i - r * n;
-        a.P[(size_t)r * a.ld + c] = (a.Pn[(size_t)r * a.ld + c] + a.Pn[(size_t)c * a.ld + r]) / 2.;
+                           for (int j = 0; j < 4; ++j) {
+                               const int r = r0 + i, c = c0 + j;
+                               if (r < n && c < n) a.Pn[(size_t)r * a.ld + c] = ((a.P[(size_t)r * a.ld + c] - t[i][j]) + (a.P[(size_t)c * a.ld + r] - t[i][j])) / 2.;
+                           }
+                   }
+               });
+    stamp(10);
+    for (int i0 = tid; i0 < n * a.ld; i0 += 8 * UT) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * UT; x[u] = i < n * a.ld ? a.Pn[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * UT; if (i < n * a.ld) a.P[i] = x[u]; }
     }
     __syncthreads();
     stamp(6);
@@ -1303,7 +1363,7 @@ __global__ __launch_bounds__(UT) void update_back_batch_kernel(const UpdArgs* __
 }
 // LDS of the two halves for a stream with m stacked rows over nc columns
 static inline size_t update_front_lds(int m) { return sizeof(double) * (2 * (size_t)m + 8); }
-static inline size_t update_back_lds(int m, int nc) { const size_t k = m > nc ? nc : m; return sizeof(double) * (k * (k + 1) / 2 + 8); }
+static inline size_t update_back_lds(int m, int nc) { const size_t k = m > nc ? nc : m; return sizeof(double) * (k * (k + 1) / 2 + 8 + 2 * (size_t)PANEL_Q * PANEL_W); }
 // The kernels with dynamic LDS are allowed the whole 160 KB once, up front: the limit is process-wide state, and the
 // stream groups of the batched filter launch concurrently from several host threads (a per-launch hipFuncSetAttribute
 // with the launch's own size could lower the limit under another thread's launch).
