@@ -183,13 +183,17 @@ def main():
         eng.push_imu_batch(i, t, gy)
         eng.step(img0[k], img1[k], frame_ts[k])
 
-    def run_filter(k, ids_h, uv_h, n_h):
+    def run_filter(k, ids_h, uv_h, n_h, queued=False):
         t1 = time.perf_counter()
         i, t, gy, ac = imu_steps[k]
         flt.push_imu(i, t, gy, ac)
         push_s[0] += time.perf_counter() - t1
         with torch.cuda.stream(filt_stream):         # the filter's kernels overlap the next frame's front-end kernels
-            flt.step(ids_h, uv_h, n_h, frame_ts[k])
+            if queued:
+                flt.submit(ids_h, uv_h, n_h, frame_ts[k])   # the stream groups run behind their own queues ...
+                flt.wait(1)                                 # ... at most one frame ahead of the slowest group
+            else:
+                flt.step(ids_h, uv_h, n_h, frame_ts[k])
         msckf_s[0] += time.perf_counter() - t1
 
     def run_pipelined(k_begin, k_end):
@@ -209,22 +213,29 @@ def main():
                     return
                 try:
                     if not err:
-                        run_filter(*item)
+                        run_filter(*item, queued=True)
                 except Exception as e:          # surfaced by the main thread after the join
                     err.append(e)
 
         th = threading.Thread(target=filter_loop, name='msckf')
         th.start()
         try:
+            # frame k+1 is enqueued before frame k's features are consumed: the read-back of k (pinned, double buffered)
+            # sits between the two steps on the stream, so the GPU never waits for this thread
+            run_fe(k_begin)
+            eng.read_features_begin(k_begin & 1)
             for k in range(k_begin, k_end):
-                run_fe(k)
-                ids_h, uv_h, n_h = eng.read_features_raw()      # D2H of frame k (synchronises the front-end stream)
-                q.put((k, ids_h.copy(), uv_h.copy(), n_h.copy()))
+                if k + 1 < k_end:
+                    run_fe(k + 1)
+                    eng.read_features_begin((k + 1) & 1)
+                ids_h, uv_h, n_h = eng.read_features_end(k & 1)      # waits for frame k's copy only; fresh host arrays
+                q.put((k, ids_h, uv_h, n_h))
         finally:
             q.put(None)
             th.join()
         if err:
             raise err[0]
+        flt.wait(0)                                             # the last queued step retires inside the timed region
 
     def run(k, filt=True):
         run_fe(k)

@@ -160,6 +160,11 @@ int av_frontend_max_features(const av_frontend* fe);
  * cap must be >= av_frontend_max_features.  Returns AV_E_CAPACITY if any stream overflowed a
  * device-side buffer during the step (results of that stream are then not parity-exact). */
 int av_frontend_read_features(av_frontend* fe, int64_t* ids_out, double* uv_out, int32_t* n_out, int cap, void* stream);
+/* The same read-back in two halves: _begin enqueues the device-to-host copies into pinned slot 0/1 behind the work
+ * already on `stream` and returns; _end waits for those copies only and unpacks them.  Enqueueing the next
+ * av_frontend_step between the two overlaps it with the consumption of this frame's features. */
+int av_frontend_read_features_begin(av_frontend* fe, int slot, void* stream);
+int av_frontend_read_features_end(av_frontend* fe, int slot, int64_t* ids_out, double* uv_out, int32_t* n_out, int cap);
 
 /* Pipeline state visible to callers (pipeline.py:33-40): the grid of the frame just published
  * (= prev_features after the callback returns).  Per feature k of stream `stream`:
@@ -245,6 +250,15 @@ int  av_msckf_batch_push_imu(av_msckf_batch* b, const int32_t* stream_idx, const
  * uv[(s*cap+k)*4..] = u0 v0 u1 v1.  out[s*12..] = {published (0/1), t, p[3], q[4] (JPL xyzw), v[3]}. */
 int  av_msckf_batch_step(av_msckf_batch* b, const int64_t* ids, const double* uv, const int32_t* n_feat, int cap,
                          const double* timestamps, double* out, void* stream);
+/* The same step, queued: returns at once; the stream groups of the batch consume their queues independently (a group
+ * that is done with frame k starts frame k+1 without waiting for the slowest group, the way the reference's VIO
+ * thread runs behind a queue, modules/vio.py:46-58).  All buffers of a submitted step, inputs and `out`, must stay
+ * valid until av_msckf_batch_wait has let it retire.  Steps retire in submission order.
+ * av_msckf_batch_wait blocks until at most max_pending submitted steps are unfinished (0 = drain) and returns the
+ * first error any of them raised (later queued steps are then skipped). */
+int  av_msckf_batch_submit(av_msckf_batch* b, const int64_t* ids, const double* uv, const int32_t* n_feat, int cap,
+                           const double* timestamps, double* out, void* stream);
+int  av_msckf_batch_wait(av_msckf_batch* b, int max_pending);
 int  av_msckf_batch_get_cov(av_msckf_batch* b, int stream_idx, double* P_host, int n, void* stream);
 int  av_msckf_batch_sizes(av_msckf_batch* b, int stream_idx, int32_t out3[3]);     /* [state dim, camera states, map features] */
 

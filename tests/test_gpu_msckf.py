@@ -284,3 +284,56 @@ def test_batched_filter_1500_features_per_frame(cfg):
     P, Po = bat.get_cov(0), ora.state_cov
     assert np.abs(P - Po).max() <= 1e-6 * np.abs(Po).max()
     bat.close()
+
+
+def test_queued_steps_run_ahead_and_match_the_oracle(cfg, monkeypatch):
+    """av_msckf_batch_submit / _wait: the two stream groups consume their queues independently (up to one frame apart);
+    every retired step must equal the oracle's, exactly as with the blocking step."""
+    from oracle.msckf_np import OracleMSCKF
+    from uav_airvision_amd.msckf_ops import BatchedMSCKF
+    from uav_airvision_amd.synth import SyntheticFeatureStream
+    monkeypatch.setenv('AV_MSCKF_GROUPS', '2')
+    n_frames = 45
+    streams = [SyntheticFeatureStream(cfg, seed=51 + i, n_frames=n_frames, n_features=60 + 30 * i) for i in range(4)]
+    S = len(streams)
+    bat = BatchedMSCKF(cfg, S)
+    oras = [OracleMSCKF(cfg) for _ in streams]
+    its = [iter(s.imu) for s in streams]
+    pend = [next(it, None) for it in its]
+    cap = 192
+    outs, refs = [], []
+    for k in range(n_frames):
+        msgs = [s.frame(k) for s in streams]
+        si, ts, gy, ac = [], [], [], []
+        for i, m in enumerate(msgs):
+            while pend[i] is not None and pend[i].timestamp <= m.timestamp:
+                oras[i].imu_callback(pend[i])
+                si.append(i); ts.append(pend[i].timestamp); gy.append(pend[i].angular_velocity); ac.append(pend[i].linear_acceleration)
+                pend[i] = next(its[i], None)
+        if si:
+            bat.push_imu(si, ts, gy, ac)
+        ids = np.zeros((S, cap), np.int64); uv = np.zeros((S, cap, 4)); nf = np.zeros(S, np.int32)
+        for i, m in enumerate(msgs):
+            nf[i] = len(m.features)
+            for j, f in enumerate(m.features):
+                ids[i, j] = f.id; uv[i, j] = (f.u0, f.v0, f.u1, f.v1)
+        outs.append(bat.submit(ids, uv, nf, [m.timestamp for m in msgs]))
+        bat.wait(1)
+        row = []
+        for i, m in enumerate(msgs):
+            r = oras[i].feature_callback(m)
+            s = oras[i].imu_state
+            row.append((r is not None, s.position.copy(), s.orientation.copy(), s.velocity.copy()))
+        refs.append(row)
+    bat.wait(0)
+    for k in range(n_frames):
+        for i in range(S):
+            pub, p, q, v = refs[k][i]
+            assert bool(outs[k][i, 0]) == pub, (k, i)
+            if pub:
+                err = max(np.abs(outs[k][i, 2:5] - p).max(), np.abs(outs[k][i, 5:9] - q).max(), np.abs(outs[k][i, 9:12] - v).max())
+                assert err < 1e-6, (k, i, err)
+    for i in range(S):
+        P, Po = bat.get_cov(i), oras[i].state_cov
+        assert np.abs(P - Po).max() <= 1e-6 * np.abs(Po).max()
+    bat.close()

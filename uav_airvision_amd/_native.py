@@ -65,6 +65,8 @@ SIGNATURES = {
     'av_frontend_step_host': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double), _P]),
     'av_frontend_max_features': (C.c_int, [_P]),
     'av_frontend_read_features': (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
+    'av_frontend_read_features_begin': (C.c_int, [_P, C.c_int, _P]),
+    'av_frontend_read_features_end': (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
     'av_frontend_read_grid': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64), _P]),
     'av_frontend_read_counters': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32 * 8), _P]),
     'av_msckf_create': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(_P)]),
@@ -84,6 +86,8 @@ SIGNATURES = {
     'av_msckf_batch_destroy': (None, [_P]),
     'av_msckf_batch_push_imu': (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     'av_msckf_batch_step': (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P]),
+    'av_msckf_batch_submit': (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P]),
+    'av_msckf_batch_wait': (C.c_int, [_P, C.c_int]),
     'av_msckf_batch_get_cov': (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     'av_msckf_batch_sizes': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32 * 3)]),
     'av_frontend_enable_timing': (C.c_int, [_P, C.c_int]),

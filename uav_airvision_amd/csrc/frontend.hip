@@ -505,7 +505,10 @@ struct av_frontend {
     int parity = 0;                    // index of the "prev" grid buffer; cam0 prev pyramid slot
     std::vector<StreamHost> streams;
     bool any_first = true;
-    std::vector<long long> h_ids; std::vector<double> h_uv; std::vector<int> h_n;
+    // feature read-back: two pinned staging slots (n | ids | uv | counters) so that the copy of frame k can be in flight
+    // behind the kernels of frame k+1 (av_frontend_read_features_begin / _end)
+    struct ReadSlot { int* n = nullptr; long long* ids = nullptr; double* uv = nullptr; int* cnt = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
+    ReadSlot rd[2];
     // optional HIP-event timing per kernel class (bench.py's roofline leg)
     bool timing = false;
     std::vector<hipEvent_t> ev; std::vector<int> ev_cls; size_t ev_used = 0;
@@ -744,7 +747,18 @@ AV_EXPORT int av_frontend_create(const av_frontend_config* cfg, int n_streams, i
             return AV_E_HIP;
         }
     }
-    fe->h_ids.resize((size_t)S * d.MAXF); fe->h_uv.resize((size_t)4 * S * d.MAXF); fe->h_n.resize(S);
+    for (int i = 0; i < 2; ++i) {
+        av_frontend::ReadSlot& r = fe->rd[i];
+        if (hipHostMalloc((void**)&r.n, sizeof(int) * S, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void**)&r.ids, sizeof(long long) * (size_t)S * d.MAXF, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void**)&r.uv, sizeof(double) * 4 * (size_t)S * d.MAXF, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void**)&r.cnt, sizeof(int) * (size_t)S * NCNT, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&r.ev, hipEventDisableTiming) != hipSuccess) {
+            av_set_error("av_frontend_create: pinned read-back staging allocation failed");
+            av_frontend_destroy(fe);
+            return AV_E_HIP;
+        }
+    }
     *out = fe;
     return AV_OK;
 }
@@ -759,6 +773,14 @@ AV_EXPORT void av_frontend_destroy(av_frontend* fe)
     if (fe->stage_img) (void)hipFree(fe->stage_img);
     for (int i = 0; i < 8; ++i) {
         if (fe->hH[i]) { (void)hipHostFree(fe->hH[i]); (void)hipEventDestroy(fe->hH_ev[i]); }
+    }
+    for (int i = 0; i < 2; ++i) {
+        av_frontend::ReadSlot& r = fe->rd[i];
+        if (r.n) (void)hipHostFree(r.n);
+        if (r.ids) (void)hipHostFree(r.ids);
+        if (r.uv) (void)hipHostFree(r.uv);
+        if (r.cnt) (void)hipHostFree(r.cnt);
+        if (r.ev) (void)hipEventDestroy(r.ev);
     }
     delete fe;
 }
@@ -812,30 +834,53 @@ AV_EXPORT int av_frontend_step_host(av_frontend* fe, const uint8_t* img0_host, c
 
 AV_EXPORT int av_frontend_max_features(const av_frontend* fe) { return fe ? fe->d.MAXF : AV_E_INVALID; }
 
-AV_EXPORT int av_frontend_read_features(av_frontend* fe, int64_t* ids_out, double* uv_out, int32_t* n_out, int cap, void* stream)
+// Read-back in two halves.  _begin enqueues the device-to-host copies of the features published by the last step into
+// pinned slot `slot` (0/1) behind everything already on `stream` and returns; _end waits for exactly those copies and
+// unpacks them into the caller's arrays.  A caller that enqueues the NEXT step between the two keeps the GPU busy while
+// it consumes this frame's features.
+AV_EXPORT int av_frontend_read_features_begin(av_frontend* fe, int slot, void* stream)
 {
-    if (!fe || !ids_out || !uv_out || !n_out || cap < fe->d.MAXF) { av_set_error("av_frontend_read_features: bad arguments"); return AV_E_INVALID; }
+    if (!fe || slot < 0 || slot > 1) { av_set_error("av_frontend_read_features_begin: bad arguments"); return AV_E_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     const FeDev& d = fe->d;
+    av_frontend::ReadSlot& r = fe->rd[slot];
     AV_HIP(hipSetDevice(fe->device));
-    AV_HIP(hipMemcpyAsync(fe->h_n.data(), d.out_n, sizeof(int) * d.S, hipMemcpyDeviceToHost, st));
-    AV_HIP(hipMemcpyAsync(fe->h_ids.data(), d.out_ids, sizeof(long long) * d.S * d.MAXF, hipMemcpyDeviceToHost, st));
-    AV_HIP(hipMemcpyAsync(fe->h_uv.data(), d.out_uv, sizeof(double) * 4 * d.S * d.MAXF, hipMemcpyDeviceToHost, st));
-    std::vector<int> cnt((size_t)d.S * NCNT);
-    AV_HIP(hipMemcpyAsync(cnt.data(), d.counters, sizeof(int) * d.S * NCNT, hipMemcpyDeviceToHost, st));
-    AV_HIP(hipStreamSynchronize(st));
+    AV_HIP(hipMemcpyAsync(r.n, d.out_n, sizeof(int) * d.S, hipMemcpyDeviceToHost, st));
+    AV_HIP(hipMemcpyAsync(r.ids, d.out_ids, sizeof(long long) * d.S * d.MAXF, hipMemcpyDeviceToHost, st));
+    AV_HIP(hipMemcpyAsync(r.uv, d.out_uv, sizeof(double) * 4 * d.S * d.MAXF, hipMemcpyDeviceToHost, st));
+    AV_HIP(hipMemcpyAsync(r.cnt, d.counters, sizeof(int) * d.S * NCNT, hipMemcpyDeviceToHost, st));
+    AV_HIP(hipEventRecord(r.ev, st));
+    r.pending = true;
+    return AV_OK;
+}
+
+AV_EXPORT int av_frontend_read_features_end(av_frontend* fe, int slot, int64_t* ids_out, double* uv_out, int32_t* n_out, int cap)
+{
+    if (!fe || slot < 0 || slot > 1 || !ids_out || !uv_out || !n_out || cap < fe->d.MAXF) { av_set_error("av_frontend_read_features_end: bad arguments"); return AV_E_INVALID; }
+    const FeDev& d = fe->d;
+    av_frontend::ReadSlot& r = fe->rd[slot];
+    if (!r.pending) { av_set_error("av_frontend_read_features_end: no read-back was begun on slot %d", slot); return AV_E_INVALID; }
+    AV_HIP(hipSetDevice(fe->device));
+    AV_HIP(hipEventSynchronize(r.ev));
+    r.pending = false;
     int ovf = 0;
+#pragma omp parallel for schedule(static) num_threads(d.S >= 64 ? 4 : 1) reduction(|:ovf)
     for (int s = 0; s < d.S; ++s) {
-        int n = fe->h_n[s];
+        const int n = r.n[s];
         n_out[s] = n;
-        for (int k = 0; k < n; ++k) {
-            ids_out[(size_t)s * cap + k] = fe->h_ids[(size_t)s * d.MAXF + k];
-            for (int j = 0; j < 4; ++j) uv_out[((size_t)s * cap + k) * 4 + j] = fe->h_uv[((size_t)s * d.MAXF + k) * 4 + j];
-        }
-        ovf |= cnt[(size_t)s * NCNT + CNT_OVF];
+        memcpy(ids_out + (size_t)s * cap, r.ids + (size_t)s * d.MAXF, sizeof(long long) * (size_t)n);
+        memcpy(uv_out + (size_t)s * cap * 4, r.uv + (size_t)s * d.MAXF * 4, sizeof(double) * 4 * (size_t)n);
+        ovf |= r.cnt[(size_t)s * NCNT + CNT_OVF];
     }
     if (ovf) { av_set_error("front-end device buffer overflow (flags 0x%x): raise max_corners", ovf); return AV_E_CAPACITY; }
     return AV_OK;
+}
+
+AV_EXPORT int av_frontend_read_features(av_frontend* fe, int64_t* ids_out, double* uv_out, int32_t* n_out, int cap, void* stream)
+{
+    int rc = av_frontend_read_features_begin(fe, 0, stream);
+    if (rc) return rc;
+    return av_frontend_read_features_end(fe, 0, ids_out, uv_out, n_out, cap);
 }
 
 AV_EXPORT int av_frontend_read_grid(av_frontend* fe, int stream_idx, int64_t* ids, int32_t* lifetime, int32_t* cell,

@@ -142,6 +142,23 @@ class FrontendEngine(object):
                                                       self._n.ctypes.data_as(C.c_void_p), self.max_features, self._stream()))
         return self._ids, self._uv, self._n
 
+    def read_features_begin(self, slot=0):
+        """Enqueue the device-to-host copy of the features published by the last step into pinned slot 0/1 (returns
+        at once).  Call `step` for the next frame before `read_features_end(slot)` to overlap the two."""
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_frontend_read_features_begin(self._h, int(slot), self._stream()))
+
+    def read_features_end(self, slot=0):
+        """Wait for the copy begun on `slot` and return NEW host arrays (ids int64[S,cap], uv float64[S,cap,4],
+        n int32[S]); entries beyond n[s] are unspecified."""
+        ids = np.empty((self.n_streams, self.max_features), np.int64)
+        uv = np.empty((self.n_streams, self.max_features, 4), np.float64)
+        n = np.empty(self.n_streams, np.int32)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_frontend_read_features_end(self._h, int(slot), ids.ctypes.data_as(C.c_void_p), uv.ctypes.data_as(C.c_void_p),
+                                                        n.ctypes.data_as(C.c_void_p), self.max_features))
+        return ids, uv, n
+
     def read_grid(self, stream=0):
         cap = self.max_features
         ids = np.zeros(cap, np.int64); life = np.zeros(cap, np.int32); cell = np.zeros(cap, np.int32)

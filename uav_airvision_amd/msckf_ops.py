@@ -162,6 +162,7 @@ class BatchedMSCKF(object):
         rt = np.concatenate([T_cam0_imu[:3, :3].T.reshape(-1), T_cam0_imu[:3, 3]])
         o = config.optimization_config
         self._h = C.c_void_p()
+        self._inflight = []
         with torch.cuda.device(self.device):
             N.check(N.lib().av_msckf_batch_create(
                 self.S, int(config.max_cam_state_size), int(rows_cap), _d(table), _d(config.gravity),
@@ -174,6 +175,9 @@ class BatchedMSCKF(object):
 
     def close(self):
         if self._h:
+            if getattr(self, '_inflight', None):
+                N.lib().av_msckf_batch_wait(self._h, 0)          # queued steps still reference the arrays in _inflight
+                self._inflight = []
             N.lib().av_msckf_batch_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -205,6 +209,28 @@ class BatchedMSCKF(object):
                                                 nf.ctypes.data_as(C.c_void_p), cap, ts.ctypes.data_as(C.c_void_p),
                                                 out.ctypes.data_as(C.c_void_p), N.current_stream()))
         return out
+
+    def submit(self, ids, uv, n_feat, timestamps):
+        """Queue one step (av_msckf_batch_submit) and return its float64[S,12] output array, which is filled once the
+        step has retired -- i.e. after a `wait(k)` that leaves fewer than the steps submitted after it pending.  The
+        stream groups of the batch run behind their queues independently of each other."""
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        uv = np.ascontiguousarray(uv, dtype=np.float64)
+        nf = np.ascontiguousarray(n_feat, dtype=np.int32)
+        ts = np.ascontiguousarray(timestamps, dtype=np.float64)
+        out = np.zeros((self.S, 12))
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_msckf_batch_submit(self._h, ids.ctypes.data_as(C.c_void_p), uv.ctypes.data_as(C.c_void_p),
+                                                  nf.ctypes.data_as(C.c_void_p), ids.shape[1], ts.ctypes.data_as(C.c_void_p),
+                                                  out.ctypes.data_as(C.c_void_p), N.current_stream()))
+        self._inflight.append((ids, uv, nf, ts, out))          # the library reads / writes these until the step retires
+        return out
+
+    def wait(self, max_pending=0):
+        """Block until at most `max_pending` submitted steps are unfinished; raises the first error of a retired step."""
+        N.check(N.lib().av_msckf_batch_wait(self._h, int(max_pending)))
+        while len(self._inflight) > max_pending:
+            self._inflight.pop(0)
 
     def sizes(self, s):
         o = (C.c_int32 * 3)()
