@@ -337,3 +337,39 @@ def test_queued_steps_run_ahead_and_match_the_oracle(cfg, monkeypatch):
         P, Po = bat.get_cov(i), oras[i].state_cov
         assert np.abs(P - Po).max() <= 1e-6 * np.abs(Po).max()
     bat.close()
+
+
+def test_queued_step_errors_surface_at_wait(cfg, monkeypatch):
+    """A capacity error raised inside a queued step (here: more stacked rows than rows_cap) is reported by the wait that
+    retires it, with the library's message, and the batch can still be closed."""
+    from uav_airvision_amd._native import AirvisionError
+    from uav_airvision_amd.msckf_ops import BatchedMSCKF
+    from uav_airvision_amd.synth import SyntheticFeatureStream
+    monkeypatch.setenv('AV_MSCKF_GROUPS', '2')
+    streams = [SyntheticFeatureStream(cfg, seed=71 + i, n_frames=30, n_features=100) for i in range(2)]
+    bat = BatchedMSCKF(cfg, 2, rows_cap=64)
+    its = [iter(s.imu) for s in streams]
+    pend = [next(it, None) for it in its]
+    raised = None
+    for k in range(30):
+        msgs = [s.frame(k) for s in streams]
+        si, ts, gy, ac = [], [], [], []
+        for i, m in enumerate(msgs):
+            while pend[i] is not None and pend[i].timestamp <= m.timestamp:
+                si.append(i); ts.append(pend[i].timestamp); gy.append(pend[i].angular_velocity); ac.append(pend[i].linear_acceleration)
+                pend[i] = next(its[i], None)
+        if si:
+            bat.push_imu(si, ts, gy, ac)
+        ids = np.zeros((2, 128), np.int64); uv = np.zeros((2, 128, 4)); nf = np.zeros(2, np.int32)
+        for i, m in enumerate(msgs):
+            nf[i] = len(m.features)
+            for j, f in enumerate(m.features):
+                ids[i, j] = f.id; uv[i, j] = (f.u0, f.v0, f.u1, f.v1)
+        bat.submit(ids, uv, nf, [m.timestamp for m in msgs])
+        try:
+            bat.wait(1)
+        except AirvisionError as e:
+            raised = e
+            break
+    assert raised is not None and 'rows_cap' in str(raised)
+    bat.close()

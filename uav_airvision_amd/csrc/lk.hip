@@ -1,4 +1,4 @@
-// lk.hip -- pyramidal iterative Lucas-Kanade tracker for gfx950, one wavefront per point.
+// lk.hip -- pyramidal iterative Lucas-Kanade tracker for gfx950, 16 lanes per point.
 //
 // Replaces cv2.calcOpticalFlowPyrLK as the reference calls it (winSize 15x15, maxLevel 3,
 // criteria (EPS|COUNT, 30, 0.01), OPTFLOW_USE_INITIAL_FLOW, minEigThreshold 1e-4):
@@ -13,24 +13,28 @@
 // eps^2 and the oscillation stop, status decided at level 0 only.
 //
 // MI355X mapping
-//   * one 64-lane wavefront owns one point for all pyramid levels (levels are a dependent chain
-//     per point, points are independent) -> no inter-workgroup synchronisation, one launch per
-//     LK call for every stream of the batch; 4 points per 256-thread workgroup.
-//   * lane map: window row r = lane>>2, columns 4q..4q+3 with q = lane&3 (4 adjacent pixels per
-//     lane); the I patch and its two derivative patches live in 12 VGPRs per lane per level.
+//   * one DPP row (16 lanes) owns one point for all pyramid levels (levels are a dependent chain per
+//     point, points are independent): 4 points per wavefront, 16 per 256-thread workgroup, no
+//     inter-workgroup synchronisation, one launch per LK call for every stream of the batch.
+//   * lane r of a row owns window row r (15 pixels; lane 15 only feeds the interpolation of row 14).
+//     The I patch and its two derivative patches live in 45 VGPRs per lane per level.  The float
+//     Newton update of a point is identical in all its lanes, so one VALU instruction serves 4 points
+//     (an earlier one-wavefront-per-point version spent half of every iteration on that replicated math).
 //   * windows are staged through LDS: per level one coalesced 18x24-byte stage of the I
 //     neighbourhood and one 32x32-byte stage of J around the predicted position (aligned dword
-//     loads, 8 lanes per image row); every Newton iteration then reads two aligned dword pairs
-//     from LDS per lane instead of 16 byte gathers from global memory.  The J tile is restaged only
-//     when the window drifts more than ~6 px (wave-uniform branch).  1152 B of LDS per wavefront.
-//   * Scharr derivatives are computed on the fly from the staged neighbourhood instead of
-//     materialising OpenCV's int16x2 derivative image (saves 4 B/pixel/level of HBM traffic).
+//     loads); every Newton iteration then reads 5 dwords of its row from LDS and takes the row below
+//     from the neighbouring lane (DPP row_shl).  The J tile is restaged only when the window drifts
+//     more than ~6 px.  1152 B of LDS per point.
+//   * Scharr derivatives are computed on the fly from the staged neighbourhood (packed 16-bit
+//     arithmetic on the even columns, odd pairs by v_perm) instead of materialising OpenCV's int16x2
+//     derivative image (saves 4 B/pixel/level of HBM traffic).
 //   * pyramid levels carry a 16-pixel reflect-101 frame, so no tap is ever clamped.
-//   * the window sums are sums of integers; they are accumulated exactly (int32 per lane and per
-//     16-lane DPP row, int64 across rows via v_readlane) and rounded once, which makes the result
-//     independent of the reduction order and bit-identical to the scalar CPU oracle.
-// Bound: VALU issue + LDS (the staged tiles come from L2: the padded pyramids of a stream are
-// ~560 KB); HBM sees each pyramid once per frame.
+//   * the window sums are sums of integers; they are accumulated exactly (int32 per lane; across the
+//     16 lanes by a DPP butterfly whose last two steps run on 16-bit halves, recombined in fp64)
+//     and rounded once, which makes the result independent of the reduction order and bit-identical
+//     to the scalar CPU oracle.
+// Bound: VALU issue (PMC: ~1,400 VALU instructions per point pass; the staged tiles come from
+// L2/MALL: the padded pyramids of a stream are ~560 KB); HBM sees each pyramid once per frame.
 #include <stdlib.h>
 
 #include "av_common.h"
@@ -50,24 +54,6 @@ struct LKArgs {
     int max_iter;
     double eps2, min_eig;
 };
-
-// ---- wave-level exact integer reduction ------------------------------------------------------
-// 16-lane DPP butterfly in int32 (bounded: 16 lanes x 4 px x 8160 x 4080 = 2,130,739,200 < 2^31),
-// then the four row sums are read into SGPRs and added in int64 (wave-uniform result).
-__device__ __forceinline__ int row_sum16(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror
-    return v;
-}
-__device__ __forceinline__ long long wave_sum_exact(int v)
-{
-    v = row_sum16(v);
-    return (long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16) +
-           (long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48);
-}
 
 // LDS traffic of one wave is ordered by issue; this keeps the compiler from moving a read of the
 // staged tile above the (other lanes') writes that fill it.
@@ -91,223 +77,6 @@ __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)l
 constexpr int TILE = 32;          // staged tile: 32 rows x 32 bytes
 constexpr int TPITCH = 36;        // LDS row pitch in bytes (9 dwords: spreads rows over banks)
 constexpr int TILE_DWORDS = TILE * TPITCH / 4;
-
-// Lane map: r = lane >> 2 is the window row (0..14 active, 15 = spare), q = lane & 3 selects window
-// columns 4q..4q+3 (column 15 is spare).  Each lane owns 4 horizontally adjacent pixels.
-template <int WIN>
-__global__ __launch_bounds__(256) void lk_track_kernel(LKArgs a)
-{
-    static_assert(WIN == 15, "lane map is built for the reference's 15x15 window");
-    constexpr int W_BITS = 14;
-    __shared__ uint32_t tile_all[4][TILE_DWORDS];
-    const int lane = threadIdx.x & 63;
-    uint32_t* tile = tile_all[threadIdx.x >> 6];
-    const int s = blockIdx.y;
-    const int pidx = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n = min(a.count[s], a.cap);
-    if (pidx >= n) return;                          // wave-uniform
-
-    const uint8_t* PI = a.pyrI + s * a.stream_stride;
-    const uint8_t* PJ = a.pyrJ + s * a.stream_stride;
-    const size_t pi = (size_t)s * a.cap + pidx;
-    const float prevx0 = a.prev[2 * pi], prevy0 = a.prev[2 * pi + 1];
-    float curx = a.next[2 * pi], cury = a.next[2 * pi + 1];       // nextPts[ptidx]
-
-    const int r = lane >> 2, q = lane & 3;
-    const float halfWin = (WIN - 1) * 0.5f;
-    bool ok = true;
-
-    for (int level = a.g.levels - 1; level >= 0; --level) {
-        const int w = a.g.w[level], h = a.g.h[level], pitch = a.g.pitch[level];
-        const uint8_t* I = PI + a.g.off[level] + AV_PYR_BORDER * pitch + AV_PYR_BORDER;    // interior (0,0)
-        const uint8_t* J = PJ + a.g.off[level] + AV_PYR_BORDER * pitch + AV_PYR_BORDER;
-        const int col_lo = -AV_PYR_BORDER, col_hi = pitch - AV_PYR_BORDER;                 // valid padded columns [lo, hi)
-        const float scale = (float)(1. / (1 << level));
-        float pvx = prevx0 * scale, pvy = prevy0 * scale;
-        if (level == a.g.levels - 1) { curx = curx * scale; cury = cury * scale; }
-        else                         { curx = curx * 2.f;   cury = cury * 2.f; }
-
-        pvx -= halfWin; pvy -= halfWin;
-        // every lane computes the same point position: make it visibly wave-uniform (SGPRs, scalar branches)
-        const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(pvx)), ipy = __builtin_amdgcn_readfirstlane((int)floorf(pvy));
-        if (ipx < -WIN || ipx >= w || ipy < -WIN || ipy >= h) {
-            if (level == 0) ok = false;
-            continue;
-        }
-        float fa = pvx - ipx, fb = pvy - ipy;
-        int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
-        int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
-        int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
-        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-
-        // ---- stage the 18x18 neighbourhood of the I window: rows ipy-1.., aligned dwords from cs ------
-        const int cs = (ipx - 1) & ~3;                 // <= ipx-1, multiple of 4
-        const int io = (ipx - 1) - cs;                 // 0..3: byte offset of window column -1 inside the staged row
-        wave_lds_sync();
-        {
-            uint32_t sv[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int idx = lane + 64 * k;             // 18 rows x 6 dwords = 108
-                const int row = idx / 6, dw = idx - row * 6;
-                const int c = cs + 4 * dw;
-                sv[k] = 0;
-                if (idx < 108 && c >= col_lo && c + 4 <= col_hi)
-                    sv[k] = *reinterpret_cast<const uint32_t*>(I + __mul24(ipy - 1 + row, pitch) + c);
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int idx = lane + 64 * k;
-                const int row = idx / 6, dw = idx - row * 6;
-                if (idx < 108) tile[__mul24(row, TPITCH / 4) + dw] = sv[k];
-            }
-        }
-        wave_lds_sync();
-
-        // ---- I patch + Scharr derivative patches of this lane's 4 pixels -----------------------------
-        int iv[4], ixv[4], iyv[4];
-        int a11 = 0, a12 = 0, a22 = 0;
-        {
-            // 4 staged rows r..r+3 (window rows r-1..r+2), 8 bytes starting at window column 4q-1
-            uint32_t lo[4], hi[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint32_t* rowp = tile + __mul24(r + t, TPITCH / 4) + q;       // r+t <= 18 < TILE
-                const uint32_t d0 = rowp[0], d1 = rowp[1], d2 = rowp[2];
-                lo[t] = __builtin_amdgcn_alignbyte(d1, d0, io);
-                hi[t] = __builtin_amdgcn_alignbyte(d2, d1, io);
-            }
-            // nb[t][c] = staged row r+t, byte c (c = 0..6) -> window pixel (row r-1+t, col 4q-1+c)
-            auto nb = [&](int t, int c) -> int { return c < 4 ? (int)((lo[t] >> (8 * c)) & 0xFF) : (int)((hi[t] >> (8 * (c - 4))) & 0xFF); };
-            // Scharr at window rows r, r+1 (t = 1, 2) and columns 4q..4q+4 (c = 1..5)
-            int gx[2][5], gy[2][5];
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int c = 0; c < 5; ++c) {
-                    const int t = 1 + dy, cc = 1 + c;
-                    const int X = ipx + 4 * q + c, Y = ipy + r + dy;
-                    const bool in = (unsigned)X < (unsigned)w && (unsigned)Y < (unsigned)h;
-                    const int t0l = (nb(t - 1, cc - 1) + nb(t + 1, cc - 1)) * 3 + nb(t, cc - 1) * 10;
-                    const int t0r = (nb(t - 1, cc + 1) + nb(t + 1, cc + 1)) * 3 + nb(t, cc + 1) * 10;
-                    const int t1l = nb(t + 1, cc - 1) - nb(t - 1, cc - 1);
-                    const int t1c = nb(t + 1, cc) - nb(t - 1, cc);
-                    const int t1r = nb(t + 1, cc + 1) - nb(t - 1, cc + 1);
-                    gx[dy][c] = in ? (t0r - t0l) : 0;
-                    gy[dy][c] = in ? ((t1r + t1l) * 3 + t1c * 10) : 0;
-                }
-            const uint32_t wtop = pack16(iw00, iw01), wbot = pack16(iw10, iw11);     // weights <= 16384 fit i16
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool act = (r < WIN) && (4 * q + j < WIN);
-                const int c = 1 + j;
-                // all products are exact in dot2: |pixel| <= 255, |gradient| <= 4080, weight <= 16384
-                int ival = dot2(pack16(nb(1, c), nb(1, c + 1)), wtop, dot2(pack16(nb(2, c), nb(2, c + 1)), wbot, 1 << (W_BITS - 6))) >> (W_BITS - 5);
-                int ix = dot2(pack16(gx[0][j], gx[0][j + 1]), wtop, dot2(pack16(gx[1][j], gx[1][j + 1]), wbot, 1 << (W_BITS - 1))) >> W_BITS;
-                int iy = dot2(pack16(gy[0][j], gy[0][j + 1]), wtop, dot2(pack16(gy[1][j], gy[1][j + 1]), wbot, 1 << (W_BITS - 1))) >> W_BITS;
-                iv[j] = ival;
-                ixv[j] = act ? ix : 0;
-                iyv[j] = act ? iy : 0;
-                a11 += __mul24(ixv[j], ixv[j]);
-                a12 += __mul24(ixv[j], iyv[j]);
-                a22 += __mul24(iyv[j], iyv[j]);
-            }
-        }
-        const long long sA11 = wave_sum_exact(a11), sA12 = wave_sum_exact(a12), sA22 = wave_sum_exact(a22);
-        const double FLT_SCALE_D = 1.0 / (1 << 20);
-        const float A11 = (float)((double)sA11 * FLT_SCALE_D);
-        const float A12 = (float)((double)sA12 * FLT_SCALE_D);
-        const float A22 = (float)((double)sA22 * FLT_SCALE_D);
-
-        float D = A11 * A22 - A12 * A12;
-        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
-        if (__builtin_amdgcn_readfirstlane((int)((double)minEig < a.min_eig || D < 1.1920928955078125e-7f))) {
-            if (level == 0) ok = false;
-            continue;
-        }
-        D = 1.f / D;
-
-        float wx = curx - halfWin, wy = cury - halfWin;       // nextPt -= halfWin
-        float pdx = 0.f, pdy = 0.f;
-        int X0 = 0, Y0 = 0;                                   // origin of the staged J tile (interior coords)
-        bool staged = false;
-        for (int j = 0; j < a.max_iter; ++j) {
-            const int inx = __builtin_amdgcn_readfirstlane((int)floorf(wx)), iny = __builtin_amdgcn_readfirstlane((int)floorf(wy));
-            if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) {
-                if (level == 0) ok = false;
-                break;
-            }
-            int dx0 = inx - X0, dy0 = iny - Y0;
-            if (!staged || (unsigned)dx0 > 15u || (unsigned)dy0 > 15u) {
-                // (re)stage a 32x32 tile of J around the window, clamped to the padded level
-                X0 = min(max((inx - 6) & ~3, col_lo), col_hi - TILE);
-                Y0 = min(max(iny - 8, -AV_PYR_BORDER), h + AV_PYR_BORDER - TILE);
-                wave_lds_sync();
-                uint32_t sv[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int idx = lane + 64 * k;
-                    const int row = idx >> 3, dw = idx & 7;
-                    sv[k] = *reinterpret_cast<const uint32_t*>(J + __mul24(Y0 + row, pitch) + X0 + 4 * dw);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int idx = lane + 64 * k;
-                    tile[__mul24(idx >> 3, TPITCH / 4) + (idx & 7)] = sv[k];
-                }
-                wave_lds_sync();
-                staged = true;
-                dx0 = inx - X0; dy0 = iny - Y0;
-            }
-            fa = wx - inx; fb = wy - iny;
-            iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
-            iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
-            iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
-            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-
-            const int bo = dx0 + 4 * q;                          // byte offset of this lane's first pixel in the row
-            const int sh = bo & 3;
-            const uint32_t* rp = tile + __mul24(dy0 + r, TPITCH / 4) + (bo >> 2);
-            const uint32_t t0 = rp[0], t1 = rp[1], u0 = rp[TPITCH / 4], u1 = rp[TPITCH / 4 + 1];
-            // 8-byte windows of the two rows starting at this lane's first pixel
-            const uint32_t top = __builtin_amdgcn_alignbyte(t1, t0, sh), toph = t1 >> (8 * sh);
-            const uint32_t bot = __builtin_amdgcn_alignbyte(u1, u0, sh), both = u1 >> (8 * sh);
-            const uint32_t wtop = pack16(iw00, iw01), wbot = pack16(iw10, iw11);
-            int b1 = 0, b2 = 0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                // (pixel c | pixel c+1 << 16) of each row via one byte permute; 0x0C selects a zero byte
-                const uint32_t sel = 0x0C000C00u | (uint32_t)c | ((uint32_t)(c + 1) << 16);
-                const uint32_t tp = __builtin_amdgcn_perm(toph, top, sel);
-                const uint32_t bp = __builtin_amdgcn_perm(both, bot, sel);
-                const int v = dot2(tp, wtop, dot2(bp, wbot, 1 << (W_BITS - 6)));
-                const int diff = (v >> (W_BITS - 5)) - iv[c];
-                b1 += __mul24(diff, ixv[c]);
-                b2 += __mul24(diff, iyv[c]);
-            }
-            const long long sb1 = wave_sum_exact(b1), sb2 = wave_sum_exact(b2);
-            const float fb1 = (float)((double)sb1 * FLT_SCALE_D);
-            const float fb2 = (float)((double)sb2 * FLT_SCALE_D);
-            const float dx = (A12 * fb2 - A22 * fb1) * D;
-            const float dy = (A12 * fb1 - A11 * fb2) * D;
-            wx += dx; wy += dy;
-            curx = wx + halfWin; cury = wy + halfWin;
-            int stop = 0;
-            if ((double)dx * dx + (double)dy * dy <= a.eps2) stop = 1;
-            else if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) stop = 2;
-            stop = __builtin_amdgcn_readfirstlane(stop);
-            if (stop == 2) { curx -= dx * 0.5f; cury -= dy * 0.5f; }
-            if (stop) break;
-            pdx = dx; pdy = dy;
-        }
-    }
-    if (lane == 0) {
-        a.next[2 * pi] = curx;
-        a.next[2 * pi + 1] = cury;
-        a.status[pi] = ok ? 1 : 0;
-    }
-}
-
 
 // =================================================================================================
 // 16 lanes per point: lane r of a DPP row owns window row r (15 pixels); one wavefront tracks 4 points.
@@ -598,14 +367,8 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
     a.prev = prev; a.next = next; a.status = status; a.count = count; a.cap = cap;
     a.max_iter = p.max_iter; a.eps2 = p.eps2; a.min_eig = p.min_eig;
     if (launch_pts > cap) launch_pts = cap;
-    static const bool use_w64 = getenv("AV_LK_WAVE_PER_POINT") != nullptr;       // A/B switch: the one-wavefront-per-point kernel
-    if (use_w64) {
-        dim3 grid((launch_pts + 3) / 4, n_set);
-        hipLaunchKernelGGL(lk_track_kernel<15>, grid, dim3(256), 0, st, a);
-    } else {
-        dim3 grid((launch_pts + 15) / 16, n_set);
-        hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
-    }
+    dim3 grid((launch_pts + 15) / 16, n_set);
+    hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
