@@ -72,6 +72,15 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(av_v2s, a), __builtin_bit_cast(av_v2s, b), c, false);
 }
+// the same with the accumulator in its own register: v_dot2c (what the builtin selects) accumulates in place, so an
+// accumulator that has to survive -- the per-pixel seeds, the rounding constants -- costs a v_mov per use; the VOP3P
+// form takes it as a third source
+__device__ __forceinline__ int dot2_keep(uint32_t a, uint32_t b, int c)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
 
 constexpr int TILE = 32;          // staged tile: 32 rows x 32 bytes
@@ -241,14 +250,15 @@ __global__ __launch_bounds__(256) void lk_track_g16_kernel(LKArgs a)
                     gxp[dy][2 * k + 1] = mid(gxp[dy][2 * k], gxp[dy][2 * k + 2]);
                     gyp[dy][2 * k + 1] = mid(gyp[dy][2 * k], gyp[dy][2 * k + 2]);
                 }
+            const int rnd_i = 1 << (W_BITS - 6), rnd_d = 1 << (W_BITS - 1);      // rounding terms, one register each
 #pragma unroll
             for (int c = 0; c < WIN; ++c) {
                 const int k = c >> 1;
                 const uint32_t ptop = (c & 1) == 0 ? O12[0][k] : E[1][k + 1];
                 const uint32_t pbot = (c & 1) == 0 ? O12[1][k] : E[2][k + 1];
-                const int ival = dot2(ptop, wtop, dot2(pbot, wbot, 1 << (W_BITS - 6))) >> (W_BITS - 5);
-                ixv[c] = dot2(gxp[0][c], wtop, dot2(gxp[1][c], wbot, 1 << (W_BITS - 1))) >> W_BITS;
-                iyv[c] = dot2(gyp[0][c], wtop, dot2(gyp[1][c], wbot, 1 << (W_BITS - 1))) >> W_BITS;
+                const int ival = dot2(ptop, wtop, dot2_keep(pbot, wbot, rnd_i)) >> (W_BITS - 5);
+                ixv[c] = dot2(gxp[0][c], wtop, dot2_keep(gxp[1][c], wbot, rnd_d)) >> W_BITS;
+                iyv[c] = dot2(gyp[0][c], wtop, dot2_keep(gyp[1][c], wbot, rnd_d)) >> W_BITS;
                 // accumulator seed of the iteration's interpolation: ((dot + R) >> 9) - ival == (dot + R - (ival << 9)) >> 9
                 iv[c] = (1 << (W_BITS - 6)) - (ival << (W_BITS - 5));
                 a11 += __mul24(ixv[c], ixv[c]);
@@ -324,7 +334,7 @@ __global__ __launch_bounds__(256) void lk_track_g16_kernel(LKArgs a)
                 const uint32_t sel = 0x0C000C00u | (uint32_t)o | ((uint32_t)(o + 1) << 16);     // o+1 == 4 selects byte 0 of the next dword
                 const uint32_t tp = __builtin_amdgcn_perm(T[q + 1], T[q], sel);
                 const uint32_t bp = __builtin_amdgcn_perm(Bt[q + 1], Bt[q], sel);
-                const int diff = dot2(tp, wtop, dot2(bp, wbot, iv[c])) >> (W_BITS - 5);
+                const int diff = dot2(tp, wtop, dot2_keep(bp, wbot, iv[c])) >> (W_BITS - 5);
                 b1 += __mul24(diff, ixv[c]);
                 b2 += __mul24(diff, iyv[c]);
             }
