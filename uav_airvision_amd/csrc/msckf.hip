@@ -995,6 +995,106 @@ __device__ __forceinline__ void qr_in_registers(const UpdArgs& a, int m, int nc,
     __syncthreads();
 }
 
+
+// sum over each 32-lane half of the wavefront, returned to the lanes of that half
+__device__ __forceinline__ double half32_sum_f64(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    const double lo = lane_f64(v, 0) + lane_f64(v, 16), hi = lane_f64(v, 32) + lane_f64(v, 48);
+    return (threadIdx.x & 32) ? hi : lo;
+}
+
+// The register-resident QR for the lost-feature shape (m <= 256 rows, up to 128 columns): HALF a wavefront per column.
+// Column c lives in wavefront (c mod 32) / 2, half c & 1, slot c / 32 (4 slots); row i in lane i mod 32 of the half, slot
+// i / 32 (8 slots): 32 doubles per lane.  One dot-product reduction then serves two columns, so a reflector costs each
+// wavefront 4 reductions instead of the 8 of the one-wavefront-per-column mapping (the reductions are what a step is
+// made of), and the 8 values of v a lane needs stay in registers.
+__device__ __forceinline__ void qr_half32(const UpdArgs& a, int m, int nc, const int* srcrow, double* vb0, double* vb1, double* qsc,
+                                          double* Wt, size_t ldt, double* rcol)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hf = lane >> 5, l32 = lane & 31;
+    double x[4][8];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const int c = 2 * wave + hf + 32 * l;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = l32 + 32 * t;
+            double v = 0.0;
+            if (row < m && c <= nc) v = c < nc ? a.Hsrc[(size_t)srcrow[row] * a.ld + a.cols[c]] : a.rsrc[srcrow[row]];
+            x[l][t] = v;
+        }
+    }
+    __syncthreads();                                   // srcrow shares its LDS with the reflector buffers
+    if (a.prof && tid == 0) a.prof[1] = __builtin_amdgcn_s_memrealtime();
+    for (int j = 0; j < nc; ++j) {
+        double* vb = (j & 1) ? vb1 : vb0;
+        double* sc = qsc + 2 * (j & 1);
+        if (wave == ((j & 31) >> 1)) {
+            const int hj = j & 1, lj = j >> 5, tj = j >> 5;          // row j sits in lane j & 31 of a half, slot j >> 5
+            double part = 0, cand = 0;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) if (l == lj) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int row = l32 + 32 * t;
+                    if (row >= j) part += x[l][t] * x[l][t];
+                    if (t == tj) cand = x[l][t];
+                }
+            }
+            const double nrm2 = lane_f64(half32_sum_f64(part), 32 * hj);
+            const double ajj = lane_f64(cand, (j & 31) + 32 * hj);
+            const double nrm = sqrt(nrm2);
+            const double alpha = ajj >= 0 ? -nrm : nrm;
+            const double vtv = nrm2 - 2 * alpha * ajj + alpha * alpha;
+            if (lane == 0) { sc[0] = ajj - alpha; sc[1] = vtv > 0 ? 2.0 / vtv : 0.0; }
+            if (hf == hj) {
+#pragma unroll
+                for (int l = 0; l < 4; ++l) if (l == lj) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int row = l32 + 32 * t;
+                        if (row > j && row < m) vb[row] = x[l][t];
+                        if (row == j) x[l][t] = alpha; else if (row > j) x[l][t] = 0.0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const double v0 = sc[0], tau = sc[1];
+        double v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const int row = l32 + 32 * t; v[t] = row == j ? v0 : ((row > j && row < m) ? vb[row] : 0.0); }
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int c = 2 * wave + hf + 32 * l;
+            if (2 * wave + 1 + 32 * l > j && 2 * wave + 32 * l <= nc) {          // some column of this slot is live (wavefront-uniform)
+                double dot = 0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) dot += v[t] * x[l][t];
+                dot = half32_sum_f64(dot) * tau;
+                if (c > j && c <= nc) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) x[l][t] -= dot * v[t];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const int c = 2 * wave + hf + 32 * l;
+        if (c <= nc) {
+            double* dst = c < nc ? Wt + (size_t)c * ldt : rcol;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const int row = l32 + 32 * t; if (row < nc) dst[row] = x[l][t]; }
+        }
+    }
+    __syncthreads();
+}
+
 // The stacked update runs as two kernels per launch group: update_front (row map, gather, thin QR -> rows 0..k-1 of
 // [H_thin | r_thin] in W) and update_back (gain, covariance).  Separate kernels keep the register-resident QR and the
 // 4x4-tiled products out of each other's register allocation (fused, the compiler spilled in every phase).
@@ -1053,9 +1153,7 @@ __device__ __forceinline__ void update_front(const UpdArgs& a)
     // 2. thin QR by Householder when m > nc; afterwards rows 0..k-1 hold [H_thin | r_thin]
     if (qr_regs) {
         double* vb0 = Lp;
-        if (nc + 1 <= 128 && m <= 128) qr_in_registers<8, 2>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
-        else if (nc + 1 <= 128 && m <= 192) qr_in_registers<8, 3>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
-        else if (nc + 1 <= 128 && m <= 256) qr_in_registers<8, 4>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
+        if (nc + 1 <= 128 && m <= 256) qr_half32(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
         else if (nc + 1 <= 64 && m <= 512) qr_in_registers<4, 8>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
         else if (nc + 1 <= 32 && m <= 1024) qr_in_registers<2, 16>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
         else if (nc + 1 <= 16 && m <= 1536) qr_in_registers<1, 24>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
