@@ -255,7 +255,8 @@ int  av_msckf_batch_step(av_msckf_batch* b, const int64_t* ids, const double* uv
  * thread runs behind a queue, modules/vio.py:46-58).  All buffers of a submitted step, inputs and `out`, must stay
  * valid until av_msckf_batch_wait has let it retire.  Steps retire in submission order.
  * av_msckf_batch_wait blocks until at most max_pending submitted steps are unfinished (0 = drain) and returns the
- * first error any of them raised (later queued steps are then skipped). */
+ * first error any of them raised (later queued steps are then skipped).  av_msckf_batch_get_cov / _sizes / _push_imu for
+ * a frame whose step is already queued must not race with pending steps: drain (wait 0) before reading state. */
 int  av_msckf_batch_submit(av_msckf_batch* b, const int64_t* ids, const double* uv, const int32_t* n_feat, int cap,
                            const double* timestamps, double* out, void* stream);
 int  av_msckf_batch_wait(av_msckf_batch* b, int max_pending);
