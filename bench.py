@@ -94,7 +94,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=30)
-    ap.add_argument('--streams', type=int, default=512, help='independent stereo streams per GPU')
+    ap.add_argument('--streams', type=int, default=1024, help='independent stereo streams per GPU')
     ap.add_argument('--unique', type=int, default=4, help='distinct rendered streams (replicated with per-stream noise)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--frontend-only', action='store_true', help='time only the image front-end (BASELINE configs[1] literally: MSCKF not on the GPU)')
