@@ -1,0 +1,37 @@
+"""The bench line contract (driver-facing): the committed output of the default command carries every field the
+contract names, with consistent values.  (The bench itself needs a GPU; this checks the committed evidence.)"""
+import glob
+import json
+import os
+
+from conftest import ROOT
+
+
+def _latest():
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'bench_default_*.json')))
+    files = [f for f in files if 'under_rocprof' not in f]
+    assert files, 'no committed default bench line under profiles/'
+    return max(files, key=os.path.getmtime)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    with open(_latest()) as f:
+        lines = [l for l in f.read().splitlines() if l.strip()]
+    assert len(lines) == 1, 'bench.py prints exactly one JSON line'
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['data'] == 'synthetic' and d['vs_baseline'] is None
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] in ('reference', 'port') and c['cores'] >= 1
+    # value = streams * steps / time
+    s = d['config']['streams_per_gpu'] * d['n_gpus']
+    assert abs(d['value'] - s / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
