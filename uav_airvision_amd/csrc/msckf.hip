@@ -891,6 +891,25 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 }
 
 
+// Reflector scalars off the slow path: the owner's norm -> sqrt -> divide chain sits between two barriers of every
+// Householder step, and the IEEE fp64 sqrt / divide sequences are long dependent chains.  v_rsq_f64 / v_rcp_f64 plus two
+// Newton steps give the same values to an ulp or two, which is all a reflector needs: H = I - tau v v^T is orthogonal for
+// tau = 2 / v^T v whatever the rounding of alpha; an inexact alpha only leaves rounding-level residue below the diagonal.
+__device__ __forceinline__ void reflector_scalars(double nrm2, double ajj, double& alpha, double& v0, double& tau)
+{
+    double r = nrm2 > 0 ? __builtin_amdgcn_rsq(nrm2) : 0.0;
+    r = r * (1.5 - 0.5 * nrm2 * r * r);
+    r = r * (1.5 - 0.5 * nrm2 * r * r);
+    const double nrm = nrm2 * r;
+    alpha = ajj >= 0 ? -nrm : nrm;
+    v0 = ajj - alpha;
+    const double vtv = nrm2 - 2 * alpha * ajj + alpha * alpha;
+    double t = vtv > 0 ? __builtin_amdgcn_rcp(vtv) : 0.0;
+    t = t * (2.0 - vtv * t);
+    t = t * (2.0 - vtv * t);
+    tau = 2.0 * t;
+}
+
 // Thin Householder QR of the stacked [H | r] held entirely in registers.  Column c lives in wavefront c % 16 (slot
 // c / 16), row i in lane i % 64 (slot i / 64): CPW x RPL doubles per lane, so 16*CPW >= nc+1 and 64*RPL >= m.
 // Per reflector: the owner wavefront norms its column and publishes v (LDS, double buffered) and (v0, tau); after ONE
@@ -932,10 +951,9 @@ __device__ __forceinline__ void qr_in_registers(const UpdArgs& a, int m, int nc,
             }
             const double nrm2 = wave_sum_f64(part);
             const double ajj = __shfl(cand, j & 63, 64);
-            const double nrm = sqrt(nrm2);
-            const double alpha = ajj >= 0 ? -nrm : nrm;
-            const double vtv = nrm2 - 2 * alpha * ajj + alpha * alpha;
-            if (lane == 0) { sc[0] = ajj - alpha; sc[1] = vtv > 0 ? 2.0 / vtv : 0.0; }
+            double alpha, v0o, tauo;
+            reflector_scalars(nrm2, ajj, alpha, v0o, tauo);
+            if (lane == 0) { sc[0] = v0o; sc[1] = tauo; }
 #pragma unroll
             for (int l = 0; l < CPW; ++l) if (l == lj) {
 #pragma unroll
@@ -996,6 +1014,7 @@ __device__ __forceinline__ void qr_in_registers(const UpdArgs& a, int m, int nc,
 }
 
 
+
 // sum over each 32-lane half of the wavefront, returned to the lanes of that half
 __device__ __forceinline__ double half32_sum_f64(double v)
 {
@@ -1047,10 +1066,9 @@ __device__ __forceinline__ void qr_half32(const UpdArgs& a, int m, int nc, const
             }
             const double nrm2 = lane_f64(half32_sum_f64(part), 32 * hj);
             const double ajj = lane_f64(cand, (j & 31) + 32 * hj);
-            const double nrm = sqrt(nrm2);
-            const double alpha = ajj >= 0 ? -nrm : nrm;
-            const double vtv = nrm2 - 2 * alpha * ajj + alpha * alpha;
-            if (lane == 0) { sc[0] = ajj - alpha; sc[1] = vtv > 0 ? 2.0 / vtv : 0.0; }
+            double alpha, v0o, tauo;
+            reflector_scalars(nrm2, ajj, alpha, v0o, tauo);
+            if (lane == 0) { sc[0] = v0o; sc[1] = tauo; }
             if (hf == hj) {
 #pragma unroll
                 for (int l = 0; l < 4; ++l) if (l == lj) {
