@@ -70,14 +70,14 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t pix[PH * PW];
     __shared__ uint8_t sc[SH * SW];
-    __shared__ uint16_t cand[SH * SW];
-    __shared__ int ncand;
+    // candidate lists, one private segment per wavefront (a wavefront visits every fourth chunk of 64 positions)
+    constexpr int SEG = ((SH * SW + 255) / 256) * 64;
+    __shared__ uint16_t cand[4 * SEG];
     const int img_i = blockIdx.z;
     const uint8_t* img = a.img + img_i * a.img_stride;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int tid = threadIdx.x;
 
-    if (tid == 0) ncand = 0;
     // pixel tile: 24 rows x 72 bytes from (x0-4, y0-4).  Tiles whose footprint lies inside the (padded) image copy dwords
     // (x0 is a multiple of 64, so x0-4 is dword aligned when pitch and base are); the others clamp per byte.  Pixels
     // outside the image never reach a valid output (corners need x, y in [3, dim-3)), so clamp vs reflect is immaterial.
@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
     __syncthreads();
     // Phase 1: cheap necessary condition on the 4 compass pixels of the ring (any 9-arc contains at
     // least two of them), survivors compacted into an LDS list so that phase 2 runs dense.
-    const int lane = tid & 63;
+    const int lane = tid & 63, wave = tid >> 6;
+    int wcnt = 0;                                   // candidates found by this wavefront so far (wavefront-uniform)
     for (int i0 = 0; i0 < SH * SW; i0 += 256) {
         const int i = i0 + tid;
         bool cand_flag = false;
@@ -116,17 +117,18 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
                 cand_flag = nb >= 2 || nd >= 2;
             }
         }
+        // ordered compaction into this wavefront's own segment: no LDS atomic, no cross-lane broadcast
         const unsigned long long b = __ballot(cand_flag);
-        int base = 0;
-        if (lane == 0 && b) base = atomicAdd(&ncand, __popcll(b));
-        base = __shfl(base, 0, 64);
-        if (cand_flag) cand[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        if (cand_flag) cand[wave * SEG + wcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0))] = (uint16_t)i;
+        wcnt += __popcll(b);
     }
-    __syncthreads();
-    // Phase 2: full corner score only for the candidates
-    const int nc = ncand;
-    for (int k = tid; k < nc; k += 256) {
-        const int i = cand[k];
+    // Phase 2: full corner score only for the candidates -- each wavefront scores its own list (the LDS traffic of one
+    // wavefront is ordered, so no workgroup barrier is needed between the two phases)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int k = lane; k < wcnt; k += 64) {
+        const int i = cand[wave * SEG + k];
         const int r = i / SW, c = i - r * SW;
         sc[i] = (uint8_t)fast_score(&pix[(r + 3) * PW + (c + 3)], a.threshold);
     }
