@@ -1426,7 +1426,8 @@ __device__ __forceinline__ void update_back(const UpdArgs& a)
     //    the same order, so both halves of the symmetrisation are available to the tile that owns (r,c): it reads the
     //    4x4 tile of P and its mirror tile (both row segments of 32 B), and the transposed, uncoalesced pass over the
     //    whole matrix that the separate (P + P^T)/2 needed is gone.  Pn then holds the result; a coalesced copy moves it back.
-    panel_gemm(n, n, k, pa, pb, false,
+    //    Only the tiles on and below the diagonal are formed (half the FMAs and LDS traffic); each writes its mirror too.
+    panel_gemm(n, n, k, pa, pb, true,
                [&](int q, int r) { return a.Kt[(size_t)q * a.ld + r]; },
                [&](int q, int c) { return a.Kt[(size_t)q * a.ld + c]; },
                [&](int r0, int c0, const double (&t)[4][4]) {
@@ -1437,12 +1438,16 @@ __device__ __forceinline__ void update_back(const UpdArgs& a)
                            prow[i] = *reinterpret_cast<const av_d4*>(a.P + (size_t)(r0 + i) * a.ld + c0);
                            mrow[i] = *reinterpret_cast<const av_d4*>(a.P + (size_t)(c0 + i) * a.ld + r0);
                        }
+                       av_d4 o[4], om[4];
 #pragma unroll
-                       for (int i = 0; i < 4; ++i) {
-                           av_d4 o;
+                       for (int i = 0; i < 4; ++i)
 #pragma unroll
-                           for (int j = 0; j < 4; ++j) o[j] = ((prow[i][j] - t[i][j]) + (mrow[j][i] - t[i][j])) / 2.;
-                           *reinterpret_cast<av_d4*>(a.Pn + (size_t)(r0 + i) * a.ld + c0) = o;
+                           for (int j = 0; j < 4; ++j) { const double v = ((prow[i][j] - t[i][j]) + (mrow[j][i] - t[i][j])) / 2.; o[i][j] = v; om[j][i] = v; }
+#pragma unroll
+                       for (int i = 0; i < 4; ++i) *reinterpret_cast<av_d4*>(a.Pn + (size_t)(r0 + i) * a.ld + c0) = o[i];
+                       if (r0 != c0) {
+#pragma unroll
+                           for (int i = 0; i < 4; ++i) *reinterpret_cast<av_d4*>(a.Pn + (size_t)(c0 + i) * a.ld + r0) = om[i];
                        }
                    } else {
 #pragma unroll
@@ -1450,7 +1455,11 @@ __device__ __forceinline__ void update_back(const UpdArgs& a)
 #pragma unroll
                            for (int j = 0; j < 4; ++j) {
                                const int r = r0 + i, c = c0 + j;
-                               if (r < n && c < n) a.Pn[(size_t)r * a.ld + c] = ((a.P[(size_t)r * a.ld + c] - t[i][j]) + (a.P[(size_t)c * a.ld + r] - t[i][j])) / 2.;
+                               if (r < n && c < n) {
+                                   const double v = ((a.P[(size_t)r * a.ld + c] - t[i][j]) + (a.P[(size_t)c * a.ld + r] - t[i][j])) / 2.;
+                                   a.Pn[(size_t)r * a.ld + c] = v;
+                                   a.Pn[(size_t)c * a.ld + r] = v;
+                               }
                            }
                    }
                });
