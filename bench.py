@@ -46,7 +46,7 @@ def make_config():
     return ConfigEuRoC(grid_row=4, grid_col=5, grid_min_feature_num=3, grid_max_feature_num=15)
 
 
-def cpu_baseline(cfg, with_msckf, budget_s=10.0, max_frames=400):
+def cpu_baseline(cfg, with_msckf, budget_s=10.0, max_frames=400, seed=0):
     """The CPU oracle (oracle/: scalar C image ops + Python glue + numpy MSCKF = a port of the reference's
     CPU path) on ONE stream of the same workload, single thread, bounded sample."""
     from oracle.frontend import OracleFrontend
@@ -57,7 +57,7 @@ def cpu_baseline(cfg, with_msckf, budget_s=10.0, max_frames=400):
         threadpool_limits(1)
     except Exception:
         pass
-    st = SyntheticStream(cfg, seed=0, n_frames=max_frames)
+    st = SyntheticStream(cfg, seed=seed, n_frames=max_frames)
     frames = []
     fe = OracleFrontend(cfg, cache_pyramids=True)
     flt = OracleMSCKF(cfg) if with_msckf else None
@@ -89,6 +89,30 @@ def cpu_baseline(cfg, with_msckf, budget_s=10.0, max_frames=400):
                        % (n, warm, spent, int(np.mean(frames)), 'front-end + MSCKF' if with_msckf else 'front-end only'))
 
 
+def cpu_baseline_all_cores(with_msckf, budget_s=6.0):
+    """The same single-thread port, one independent stream per host core in parallel child processes (they never touch the
+    GPU): the CPU box's aggregate rate on this workload, for context next to the one-core figure."""
+    import subprocess
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    n = max(1, min(16, n))                     # a GPU box gives one GPU's job a share of 16 cores
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--cpu-budget', str(budget_s)]
+    if not with_msckf:
+        cmd.append('--frontend-only')
+    procs = [subprocess.Popen(cmd + ['--cpu-seed', str(100 + i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(n)]
+    vals = []
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        if p.returncode == 0 and out.strip():
+            vals.append(json.loads(out.strip().splitlines()[-1])['value'])
+    if not vals:
+        return None
+    return dict(value=float(sum(vals)), unit='stereo frames/s', cores=len(vals), kind='port',
+                sample='%d concurrent single-thread ports, one synthetic stream each, %.0f s of CPU per process' % (len(vals), budget_s))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -97,8 +121,14 @@ def main():
     ap.add_argument('--streams', type=int, default=1024, help='independent stereo streams per GPU')
     ap.add_argument('--unique', type=int, default=4, help='distinct rendered streams (replicated with per-stream noise)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-budget', type=float, default=6.0, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-seed', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--frontend-only', action='store_true', help='time only the image front-end (BASELINE configs[1] literally: MSCKF not on the GPU)')
     args = ap.parse_args()
+    if args.cpu_baseline_worker:               # child of cpu_baseline_all_cores: CPU only, exits before torch is imported
+        print(json.dumps(cpu_baseline(make_config(), not args.frontend_only, budget_s=args.cpu_budget, seed=args.cpu_seed)))
+        return
 
     import torch
     import torch.distributed as dist
@@ -330,6 +360,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, with_msckf)
+            out['cpu_baseline_all_cores'] = cpu_baseline_all_cores(with_msckf)
         print(json.dumps(out))
     eng.close()
     if world > 1:
