@@ -1,9 +1,2 @@
-class FeatureMeasurement(object):
-    """Stereo measurement handed to the filter (reference: src/image_processing/feature_measurment.py:1-9)."""
-
-    def __init__(self):
-        self.id = None
-        self.u0 = None
-        self.v0 = None
-        self.u1 = None
-        self.v1 = None
+"""Import path kept from the reference (the file name's spelling included): the type lives in records.py."""
+from .records import FeatureMeasurement  # noqa: F401
