@@ -149,3 +149,51 @@ def test_engine_blank_and_late_texture_streams(cfg):
         _compare(ref, got[i], 'edge %d' % i)
     assert all(len(g[0]) == 0 for g in got[0])
     assert len(got[1][1][0]) == 0 and len(got[1][-1][0]) > 50
+
+
+def test_two_phase_read_back_matches_blocking_read_and_checks_misuse(cfg):
+    """av_frontend_read_features_begin/_end: same features as the blocking read, also when the next step is enqueued
+    between the two halves; _end without a matching _begin is an error, not a hang."""
+    import torch
+    from uav_airvision_amd._native import AirvisionError
+    from uav_airvision_amd.frontend import FrontendEngine
+    from uav_airvision_amd.synth import SyntheticStream
+    st = SyntheticStream(cfg, seed=17, n_frames=4)
+    dev = torch.device('cuda', 0)
+
+    def run(two_phase):
+        eng = FrontendEngine(cfg, n_streams=1, device=0)
+        it = iter(st.imu); pend = next(it, None)
+        out = []
+        imgs = []
+        for k in range(4):
+            m = st.frame(k)
+            imgs.append((torch.from_numpy(m.cam0_image[None]).to(dev), torch.from_numpy(m.cam1_image[None]).to(dev), m.timestamp))
+        def push(k):
+            nonlocal pend
+            idx, ts, gy = [], [], []
+            while pend is not None and pend.timestamp <= imgs[k][2]:
+                idx.append(0); ts.append(pend.timestamp); gy.append(pend.angular_velocity); pend = next(it, None)
+            if idx:
+                eng.push_imu_batch(np.array(idx, np.int32), np.array(ts), np.array(gy).reshape(-1, 3))
+        if two_phase:
+            with pytest.raises(AirvisionError):
+                eng.read_features_end(1)
+            push(0); eng.step(imgs[0][0], imgs[0][1], [imgs[0][2]]); eng.read_features_begin(0)
+            for k in range(4):
+                if k + 1 < 4:
+                    push(k + 1); eng.step(imgs[k + 1][0], imgs[k + 1][1], [imgs[k + 1][2]]); eng.read_features_begin((k + 1) & 1)
+                ids, uv, n = eng.read_features_end(k & 1)
+                out.append((ids[0, :n[0]].copy(), uv[0, :n[0]].copy()))
+        else:
+            for k in range(4):
+                push(k); eng.step(imgs[k][0], imgs[k][1], [imgs[k][2]])
+                ids, uv, n = eng.read_features_raw()
+                out.append((ids[0, :n[0]].copy(), uv[0, :n[0]].copy()))
+        eng.close()
+        return out
+
+    a, b = run(False), run(True)
+    for k in range(4):
+        assert len(a[k][0]) > 20
+        assert np.array_equal(a[k][0], b[k][0]) and np.array_equal(a[k][1].view(np.uint64), b[k][1].view(np.uint64)), k
