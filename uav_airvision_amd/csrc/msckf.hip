@@ -294,6 +294,8 @@ struct FeatArgs {
     int n_list;                          // teams to run in this launch
     int team_doubles;                    // LDS doubles per team (wavefront teams: four per workgroup)
     unsigned long long* prof;            // optional [8] phase stamps of team 0 (diagnostic runs, AV_MSCKF_TIMING)
+    int zero_fill;                       // 1: clear the full-width output rows first (columns of cameras the feature was not seen
+                                         // from must read as zero); 0: the caller gathers only this feature's own camera columns
 };
 
 // dynamic LDS of feature_kernel for tracks of at most Mx observations (layout at the top of the kernel)
@@ -507,11 +509,13 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
     if (a.prof && slot == 0 && tid == 0) a.prof[3] = __builtin_amdgcn_s_memrealtime();
     // rows 3..R4-1 of H and r are A^T H_x and A^T r.  Write them out (dense row of width ld).
     const int row0 = a.row_off[f];
-    for (int i = tid; i < K * a.ld; i += TEAM) {
-        const int rI = i / a.ld, c = i - rI * a.ld;
-        Hout[(size_t)(row0 + rI) * a.ld + c] = 0.0;
+    if (a.zero_fill) {
+        for (int i = tid; i < K * a.ld; i += TEAM) {
+            const int rI = i / a.ld, c = i - rI * a.ld;
+            Hout[(size_t)(row0 + rI) * a.ld + c] = 0.0;
+        }
+        team_sync<TEAM>();
     }
-    team_sync<TEAM>();
     for (int i = tid; i < K * C6; i += TEAM) {
         const int rI = i / C6, c = i - rI * C6;
         Hout[(size_t)(row0 + rI) * a.ld + IMU_DIM + 6 * cidx[c / 6] + c % 6] = H[(3 + rI) * C6 + c];
@@ -1694,7 +1698,7 @@ AV_EXPORT int av_msckf_feature_blocks(av_msckf* c, int n_feat, int n_cam, int ma
     for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) a.R01[r * 3 + cc] = T_cam0_cam1_rowmajor44[r * 4 + cc]; a.t01[r] = T_cam0_cam1_rowmajor44[r * 4 + 3]; a.gravity[r] = gravity[r]; }
     a.obs_noise = obs_noise; a.Hout = c->Hblk; a.rout = c->rblk; a.gamma = gamma_dev; a.pass = pass_dev; a.Mmax = max_obs;
     a.feat_stream = nullptr; a.stream_ncam = nullptr; a.stream_gravity = nullptr; a.cam_stride = 0; a.p_stride = a.h_stride = a.r_stride = 0;
-    a.feat_list = nullptr; a.prof = nullptr;
+    a.feat_list = nullptr; a.prof = nullptr; a.zero_fill = 1;
     AV_HIP(hipSetDevice(c->device));
     return launch_feature_kernel(a, n_feat, max_obs, (hipStream_t)stream);
 }
