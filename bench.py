@@ -120,6 +120,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--streams', type=int, default=1024, help='independent stereo streams per GPU')
     ap.add_argument('--unique', type=int, default=4, help='distinct rendered streams (replicated with per-stream noise)')
+    ap.add_argument('--host-images', action='store_true', help='front-end only, images handed over as host numpy arrays every step '
+                    '(av_frontend_step_host: the PCIe-inclusive rate quoted in DESIGN.md; never the contract value)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-budget', type=float, default=6.0, help=argparse.SUPPRESS)
@@ -148,7 +150,7 @@ def main():
 
     cfg = make_config()
     S, K, Wm = args.streams, args.steps, args.warmup
-    with_msckf = not args.frontend_only
+    with_msckf = not (args.frontend_only or args.host_images)
     F = Wm + K + (K if with_msckf else 0)      # a second timed loop measures the front-end alone
     # config/seed broadcast from rank 0 over RCCL (config broadcast, no data-path collective)
     from uav_airvision_amd import shard
@@ -208,10 +210,19 @@ def main():
 
     filt_stream = torch.cuda.Stream(device=dev) if flt is not None else None
 
+    host0 = host1 = None
+    if args.host_images:                         # the same frames as pageable host arrays; the device copies are dropped
+        host0, host1 = img0.cpu().numpy(), img1.cpu().numpy()
+        del img0, img1
+        torch.cuda.empty_cache()
+
     def run_fe(k):
         i, t, gy, ac = imu_steps[k]
         eng.push_imu_batch(i, t, gy)
-        eng.step(img0[k], img1[k], frame_ts[k])
+        if host0 is not None:
+            eng.step_host(host0[k], host1[k], frame_ts[k])
+        else:
+            eng.step(img0[k], img1[k], frame_ts[k])
 
     def run_filter(k, ids_h, uv_h, n_h, queued=False):
         t1 = time.perf_counter()
@@ -329,6 +340,7 @@ def main():
             'value': fps, 'unit': 'stereo frames/s', 'n_gpus': world, 'steps': K, 'warmup': Wm,
             'ms_per_step': 1e3 * elapsed / K, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'u8/int32 windows, f32 normal equations', 'data': 'synthetic',
+            'inputs': 'host numpy arrays, H2D inside the timed region (PCIe-inclusive)' if args.host_images else 'resident in HBM',
             'config': {
                 'workload': ('BASELINE configs[1] shape (synthetic 752x480 stereo streams, grid 4x5x15 = 300 features/frame): temporal LK + '
                              'stereo LK fwd/bwd + gates + FAST/grid add/prune/publish on device, ' +

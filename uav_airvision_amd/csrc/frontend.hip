@@ -497,7 +497,10 @@ struct av_frontend {
     PyrGeom geom;
     LKParams lk;
     uint8_t* pyr = nullptr;            // [S][3][lay.bytes]
-    uint8_t* stage_img = nullptr;      // [2][S][w*h] for step_host
+    // step_host staging: two slots of {pinned host, device} image pairs, a copy stream and events, so that the H2D copy of
+    // frame k+1 runs behind the kernels of frame k (pinned double-buffered H2D of frame pairs)
+    struct HostSlot { uint8_t* pin = nullptr; uint8_t* dev = nullptr; hipEvent_t copied = nullptr, consumed = nullptr; bool used = false; };
+    HostSlot hs[2]; hipStream_t copy_stream = nullptr; int hs_next = 0;
     void* zero_region = nullptr; size_t zero_bytes = 0;
     std::vector<void*> allocs;
     double* dH = nullptr;
@@ -770,7 +773,14 @@ AV_EXPORT void av_frontend_destroy(av_frontend* fe)
     (void)hipDeviceSynchronize();
     for (void* p : fe->allocs) (void)hipFree(p);
     for (hipEvent_t e : fe->ev) (void)hipEventDestroy(e);
-    if (fe->stage_img) (void)hipFree(fe->stage_img);
+    for (int i = 0; i < 2; ++i) {
+        av_frontend::HostSlot& h = fe->hs[i];
+        if (h.pin) (void)hipHostFree(h.pin);
+        if (h.dev) (void)hipFree(h.dev);
+        if (h.copied) (void)hipEventDestroy(h.copied);
+        if (h.consumed) (void)hipEventDestroy(h.consumed);
+    }
+    if (fe->copy_stream) (void)hipStreamDestroy(fe->copy_stream);
     for (int i = 0; i < 8; ++i) {
         if (fe->hH[i]) { (void)hipHostFree(fe->hH[i]); (void)hipEventDestroy(fe->hH_ev[i]); }
     }
@@ -824,12 +834,32 @@ AV_EXPORT int av_frontend_step_host(av_frontend* fe, const uint8_t* img0_host, c
     }
     hipStream_t st = (hipStream_t)stream;
     const size_t img_bytes = (size_t)fe->d.w * fe->d.h;
+    const int S = fe->d.S;
     AV_HIP(hipSetDevice(fe->device));
-    if (!fe->stage_img) AV_HIP(hipMalloc((void**)&fe->stage_img, 2 * img_bytes * fe->d.S));
-    uint8_t* s0 = fe->stage_img; uint8_t* s1 = fe->stage_img + img_bytes * fe->d.S;
-    AV_HIP(hipMemcpy2DAsync(s0, img_bytes, img0_host, (size_t)img_stride, img_bytes, fe->d.S, hipMemcpyHostToDevice, st));
-    AV_HIP(hipMemcpy2DAsync(s1, img_bytes, img1_host, (size_t)img_stride, img_bytes, fe->d.S, hipMemcpyHostToDevice, st));
-    return step_impl(fe, s0, s1, (int64_t)img_bytes, timestamps, st);
+    av_frontend::HostSlot& h = fe->hs[fe->hs_next];
+    fe->hs_next ^= 1;
+    if (!fe->copy_stream) AV_HIP(hipStreamCreateWithFlags(&fe->copy_stream, hipStreamNonBlocking));
+    if (!h.pin) {
+        AV_HIP(hipHostMalloc((void**)&h.pin, 2 * img_bytes * S, hipHostMallocDefault));
+        AV_HIP(hipMalloc((void**)&h.dev, 2 * img_bytes * S));
+        AV_HIP(hipEventCreateWithFlags(&h.copied, hipEventDisableTiming));
+        AV_HIP(hipEventCreateWithFlags(&h.consumed, hipEventDisableTiming));
+    }
+    if (h.used) AV_HIP(hipEventSynchronize(h.consumed));          // the step that last used this slot (two calls ago) has read it
+    // caller memory -> pinned slot (the caller's buffers are free again when this returns), all cores
+#pragma omp parallel for schedule(static) num_threads(S >= 16 ? 8 : 1)
+    for (int i = 0; i < 2 * S; ++i) {
+        const int s2 = i >> 1, cam = i & 1;
+        memcpy(h.pin + ((size_t)cam * S + s2) * img_bytes, (cam ? img1_host : img0_host) + (size_t)s2 * img_stride, img_bytes);
+    }
+    AV_HIP(hipMemcpyAsync(h.dev, h.pin, 2 * img_bytes * S, hipMemcpyHostToDevice, fe->copy_stream));
+    AV_HIP(hipEventRecord(h.copied, fe->copy_stream));
+    AV_HIP(hipStreamWaitEvent(st, h.copied, 0));
+    const int rc = step_impl(fe, h.dev, h.dev + img_bytes * S, (int64_t)img_bytes, timestamps, st);
+    if (rc) return rc;
+    AV_HIP(hipEventRecord(h.consumed, st));
+    h.used = true;
+    return AV_OK;
 }
 
 AV_EXPORT int av_frontend_max_features(const av_frontend* fe) { return fe ? fe->d.MAXF : AV_E_INVALID; }
