@@ -148,6 +148,9 @@ def main():
     from uav_airvision_amd.frontend import FrontendEngine
     from uav_airvision_amd.synth import SyntheticStream
 
+    if world > 1 and 'AV_HOST_THREADS' not in os.environ:
+        # the filter's bookkeeping threads of all ranks share the node's cores: keep every rank inside its share
+        os.environ['AV_HOST_THREADS'] = str(max(4, min(16, (os.cpu_count() or 16) // world)))
     cfg = make_config()
     S, K, Wm = args.streams, args.steps, args.warmup
     with_msckf = not (args.frontend_only or args.host_images)
