@@ -197,3 +197,47 @@ def test_two_phase_read_back_matches_blocking_read_and_checks_misuse(cfg):
     for k in range(4):
         assert len(a[k][0]) > 20
         assert np.array_equal(a[k][0], b[k][0]) and np.array_equal(a[k][1].view(np.uint64), b[k][1].view(np.uint64)), k
+
+
+def test_step_host_double_buffering_matches_resident_inputs(cfg):
+    """av_frontend_step_host (pinned double-buffered H2D on a copy stream) gives the same features as the step on
+    device-resident tensors, frame after frame, with the caller's host arrays overwritten right after each call."""
+    import torch
+    from uav_airvision_amd.frontend import FrontendEngine
+    from uav_airvision_amd.synth import SyntheticStream
+    S, n_frames = 3, 6
+    streams = [SyntheticStream(cfg, seed=23 + s, n_frames=n_frames) for s in range(S)]
+    dev = torch.device('cuda', 0)
+
+    def run(host):
+        eng = FrontendEngine(cfg, n_streams=S, device=0)
+        its = [iter(st.imu) for st in streams]
+        pend = [next(it, None) for it in its]
+        out = []
+        buf0 = np.zeros((S, cfg.height if hasattr(cfg, 'height') else 480, 752), np.uint8)
+        buf1 = np.zeros_like(buf0)
+        for k in range(n_frames):
+            msgs = [st.frame(k) for st in streams]
+            idx, ts, gy = [], [], []
+            for s, m in enumerate(msgs):
+                while pend[s] is not None and pend[s].timestamp <= m.timestamp:
+                    idx.append(s); ts.append(pend[s].timestamp); gy.append(pend[s].angular_velocity); pend[s] = next(its[s], None)
+            if idx:
+                eng.push_imu_batch(np.array(idx, np.int32), np.array(ts), np.array(gy).reshape(-1, 3))
+            for s, m in enumerate(msgs):
+                buf0[s] = m.cam0_image; buf1[s] = m.cam1_image
+            tss = [m.timestamp for m in msgs]
+            if host:
+                eng.step_host(buf0, buf1, tss)
+                buf0[:] = 0; buf1[:] = 255                    # the engine must have taken its copy already
+            else:
+                eng.step(torch.from_numpy(buf0.copy()).to(dev), torch.from_numpy(buf1.copy()).to(dev), tss)
+            out.append(eng.read_features())
+        eng.close()
+        return out
+
+    a, b = run(False), run(True)
+    for k in range(n_frames):
+        for s in range(S):
+            assert len(a[k][s][0]) > 20
+            assert np.array_equal(a[k][s][0], b[k][s][0]) and np.array_equal(a[k][s][1].view(np.uint64), b[k][s][1].view(np.uint64)), (k, s)
