@@ -1262,50 +1262,43 @@ __device__ __forceinline__ void panel_gemm(int R, int Cn, int Q, double* pa, dou
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tr = (R + 3) >> 2, tc = (Cn + 3) >> 2;
     const int RA = tr * 4, CB = tc * 4;
-    for (int tbase = 0; tbase < tr * tc; tbase += 2 * UT) {              // one pass for n <= 181 (2048 tiles)
-        int r0[2], c0[2]; bool act[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int t = tbase + tid + u * UT;
-            act[u] = t < tr * tc;
-            r0[u] = act[u] ? (t / tc) * 4 : 0; c0[u] = act[u] ? (t % tc) * 4 : 0;
-            if (lower_only && c0[u] > r0[u] + 3) act[u] = false;        // tile entirely above the diagonal
-        }
-        double acc[2][4][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[u][i][j] = 0.0;
-        // software pipeline: the next panel's global loads are issued into registers before the current panel is consumed
-        double ra[4], rb[4];
-        auto fetch = [&](int q0) {
-            const int qn = min(PANEL_Q, Q - q0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = lane + 64 * i;
-                ra[i] = (wave < qn && e < R) ? loadA(q0 + wave, e) : 0.0;
-                rb[i] = (wave < qn && e < Cn) ? loadB(q0 + wave, e) : 0.0;
+    // one 4x4 tile per thread and pass (n <= 141: 900 tiles of T, 666 lower tiles of the covariance -> a single pass); a
+    // small register footprint matters more here than a second tile per thread: the kernel should leave room on its CU
+    // for a wavefront of the front-end's kernels
+    int ntiles = tr * tc;
+    for (int tbase = 0; tbase < ntiles; tbase += UT) {
+        const int t = tbase + tid;
+        bool act = t < ntiles;
+        int r0 = 0, c0 = 0;
+        if (act) {
+            if (lower_only) {
+                // enumerate only the tiles on and below the diagonal: t -> (row, col) of the triangular index
+                r0 = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+                while ((r0 + 1) * (r0 + 2) / 2 <= t) ++r0;
+                while (r0 * (r0 + 1) / 2 > t) --r0;
+                c0 = t - r0 * (r0 + 1) / 2;
+                act = r0 < tr;
+                r0 *= 4; c0 *= 4;
+            } else {
+                r0 = (t / tc) * 4; c0 = (t % tc) * 4;
             }
-        };
-        fetch(0);
+        }
+        double acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
         for (int q0 = 0; q0 < Q; q0 += PANEL_Q) {
             const int qn = min(PANEL_Q, Q - q0);
             __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = lane + 64 * i;
-                if (e < RA) pa[wave * PANEL_W + e] = ra[i];
-                if (e < CB) pb[wave * PANEL_W + e] = rb[i];
+            if (wave < qn) {
+                for (int e = lane; e < RA; e += 64) pa[wave * PANEL_W + e] = e < R ? loadA(q0 + wave, e) : 0.0;
+                for (int e = lane; e < CB; e += 64) pb[wave * PANEL_W + e] = e < Cn ? loadB(q0 + wave, e) : 0.0;
             }
             __syncthreads();
-            if (q0 + PANEL_Q < Q) fetch(q0 + PANEL_Q);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (!act[u]) continue;
-                const double* ap = pa + r0[u];
-                const double* bp = pb + c0[u];
+            if (act) {
+                const double* ap = pa + r0;
+                const double* bp = pb + c0;
 #pragma unroll 4
                 for (int q = 0; q < qn; ++q) {
                     double av[4], bv[4];
@@ -1314,15 +1307,11 @@ __device__ __forceinline__ void panel_gemm(int R, int Cn, int Q, double* pa, dou
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[u][i][j] += av[i] * bv[j];
+                        for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
                 }
             }
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (!act[u]) continue;
-            out(r0[u], c0[u], acc[u]);                 // the tile's owner writes it (rows/columns beyond R / Cn are the functor's to skip)
-        }
+        if (act) out(r0, c0, acc);                  // the tile's owner writes it (rows/columns beyond R / Cn are the functor's to skip)
         __syncthreads();
     }
 }
