@@ -10,8 +10,14 @@ streams are the parallel axis).  One "step" = one stereo
     python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement).  Inputs are resident in HBM before
-the timed region; IMU samples are pushed from the host inside it (they are part of the path).
+Without a torchrun environment `--gpus N` (N > 1) starts the N ranks itself as fresh child processes (one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) BEFORE anything touches the GPU, relays rank 0's line and exits non-zero
+if any rank failed.  Prints ONE JSON line on rank 0 (contract in the task statement).  Inputs are resident in HBM
+before the timed region; IMU samples are pushed from the host inside it (they are part of the path).
+
+The timed region is always the steady state: before the `--warmup` steps the bench pre-rolls, un-timed, until every
+filter holds its full camera-state window and has run the camera pruning (PREROLL frames), so the result does not depend
+on how small `--warmup` is.
 """
 import argparse
 import json
@@ -35,6 +41,12 @@ HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/
 LK_TRAFFIC_BYTES_PER_POINT_PASS = (2 * 68263.08 + 295.15) * 1024 / 19200
 
 
+PREROLL_FULL = 24          # frames until every filter has 20 camera states and has pruned at least once (19 + margin)
+PREROLL_FE = 8             # front-end only: the feature grid is full after a few frames
+REFERENCE_FILTER_FPS_300 = 10.0   # the genuine reference MSCKF.feature_callback at 300 features/frame,
+                                  # imported unmodified, 1 thread of an 8-vCPU Xeon 2.1 GHz (filter half only; no cv2 there)
+
+
 def frame_bytes(n_t, n_trk, n_cand):
     """Algorithmic bytes of one stereo frame: 2 images + 2x3 pyramid levels + LK point passes."""
     p = n_t + 2 * n_trk + 2 * n_cand
@@ -46,9 +58,11 @@ def make_config():
     return ConfigEuRoC(grid_row=4, grid_col=5, grid_min_feature_num=3, grid_max_feature_num=15)
 
 
-def cpu_baseline(cfg, with_msckf, budget_s=10.0, max_frames=400, seed=0):
+def cpu_baseline(cfg, with_msckf, budget_s=10.0, max_frames=400, seed=0, traj_frames=0):
     """The CPU oracle (oracle/: scalar C image ops + Python glue + numpy MSCKF = a port of the reference's
-    CPU path) on ONE stream of the same workload, single thread, bounded sample."""
+    CPU path) on ONE stream of the same workload, single thread, bounded sample.  With traj_frames > 0 the first
+    traj_frames frames are always processed (whatever the budget) and their filter poses returned, so that the GPU
+    trajectory of the same stream can be compared with the CPU path's (ATE vs CPU ref)."""
     from oracle.frontend import OracleFrontend
     from oracle.msckf_np import OracleMSCKF
     from uav_airvision_amd.synth import SyntheticStream
@@ -65,7 +79,8 @@ def cpu_baseline(cfg, with_msckf, budget_s=10.0, max_frames=400, seed=0):
     pend = next(it, None)
     n = 0
     spent = 0.0
-    warm = 24 if with_msckf else 8             # grid full (~300 features) and 20 camera states before timing
+    warm = PREROLL_FULL if with_msckf else PREROLL_FE      # grid full (~300 features) and 20 camera states before timing
+    traj = []
     for k in range(max_frames):
         m = st.frame(k)
         while pend is not None and pend.timestamp <= m.timestamp:
@@ -75,18 +90,26 @@ def cpu_baseline(cfg, with_msckf, budget_s=10.0, max_frames=400, seed=0):
             pend = next(it, None)
         t0 = time.perf_counter()
         msg = fe.stereo_callback(m)
-        if flt is not None:
-            flt.feature_callback(msg)
+        res = flt.feature_callback(msg) if flt is not None else None
         dt = time.perf_counter() - t0
+        if res is not None and k < traj_frames:
+            s_ = flt.imu_state
+            traj.append([m.timestamp] + [float(v) for v in s_.position] + [float(v) for v in s_.orientation])
         if k >= warm:
             spent += dt
             n += 1
             frames.append(len(msg.features))
-            if spent >= budget_s:
+            if spent >= budget_s and k + 1 >= traj_frames:
                 break
-    return dict(value=n / spent, unit='stereo frames/s', cores=1, kind='port',
-                sample='%d frames of 1 synthetic stream after %d warm-up frames, %.1f s of CPU, mean %d features/frame, %s'
-                       % (n, warm, spent, int(np.mean(frames)), 'front-end + MSCKF' if with_msckf else 'front-end only'))
+    out = dict(value=n / spent, unit='stereo frames/s', cores=1, kind='port',
+               sample='%d frames of 1 synthetic stream after %d warm-up frames, %.1f s of CPU, mean %d features/frame, %s; for context, the '
+                      'genuine reference filter half alone (MSCKF.feature_callback imported unmodified, SURVEY.md section 6) runs %.1f frames/s '
+                      'at 300 features/frame on one 2.1 GHz Xeon thread -- its image half needs cv2, which is not installed'
+                      % (n, warm, spent, int(np.mean(frames)), 'front-end + MSCKF' if with_msckf else 'front-end only', REFERENCE_FILTER_FPS_300))
+    if traj_frames:
+        out['_traj'] = traj
+        out['_truth'] = [[st.frame_time(k)] + [float(v) for v in st.position(st.frame_time(k))] for k in range(min(traj_frames, max_frames))]
+    return out
 
 
 def cpu_baseline_all_cores(with_msckf, budget_s=6.0):
@@ -113,24 +136,101 @@ def cpu_baseline_all_cores(with_msckf, budget_s=6.0):
                 sample='%d concurrent single-thread ports, one synthetic stream each, %.0f s of CPU per process' % (len(vals), budget_s))
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a torchrun environment: start one fresh child per rank (this process has not
+    imported torch and never touches the GPU), relay rank 0's stdout, fail if any rank fails."""
+    import subprocess
+    env0 = dict(os.environ)
+    env0.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env0['MASTER_ADDR'] = '127.0.0.1'
+    env0['MASTER_PORT'] = str(_free_port())
+    env0['WORLD_SIZE'] = str(n_ranks)
+    env0['LOCAL_WORLD_SIZE'] = str(n_ranks)
+    procs = []
+    for r in range(n_ranks):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for line in (out0 or '').splitlines():          # the contract is ONE JSON line on stdout: library chatter goes to stderr
+        (sys.stdout if line.lstrip().startswith('{') else sys.stderr).write(line + '\n')
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        sys.stderr.write('bench.py: ranks failed (rank, exit code): %s\n' % bad)
+        return 1
+    return 0
+
+
+def dry_run(args):
+    """The multi-rank plumbing without a GPU (gloo): config broadcast from rank 0 -> stream partition -> barrier-bracketed
+    timed loop of no-op steps -> max-over-ranks time and sum-over-ranks counters -> ONE JSON line on rank 0.  Used by the
+    CPU test of the launcher; never a measurement (`dry_run: true`, value counts no-op steps)."""
+    import torch.distributed as dist
+    from uav_airvision_amd import shard
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    run_cfg = shard.broadcast_object({'seed': 1234, 'streams': args.streams, 'steps': args.steps, 'warmup': args.warmup} if rank == 0 else None)
+    S, K = int(run_cfg['streams']), int(run_cfg['steps'])
+    mine = shard.partition(S * world, world, rank)            # weak scaling: S streams per rank
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    done = 0
+    for _ in range(K):
+        time.sleep(0.001 * (1 + rank))                         # ranks differ: the max over ranks must win
+        done += len(mine)
+    if world > 1:
+        dist.barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0)
+    total = float(shard.sum_over_ranks([done])[0])
+    if rank == 0:
+        print(json.dumps({'metric': 'stereo frames/sec (LK+stereo+MSCKF-update) at 752x480', 'value': total / elapsed, 'unit': 'stereo frames/s',
+                          'n_gpus': world, 'steps': K, 'warmup': int(run_cfg['warmup']), 'ms_per_step': 1e3 * elapsed / K, 'higher_is_better': True,
+                          'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none', 'data': 'none', 'dry_run': True,
+                          'config': {'workload': 'dry run of the launcher and the rank plumbing (no GPU work)', 'streams_per_gpu': S,
+                                     'streams_total': int(total / K), 'seed': int(run_cfg['seed'])}}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--streams', type=int, default=1024, help='independent stereo streams per GPU')
     ap.add_argument('--unique', type=int, default=4, help='distinct rendered streams (replicated with per-stream noise)')
+    ap.add_argument('--no-stagger', action='store_true', help='start every replica at frame 0 (all filters then prune on the same frames)')
     ap.add_argument('--host-images', action='store_true', help='front-end only, images handed over as host numpy arrays every step '
                     '(av_frontend_step_host: the PCIe-inclusive rate quoted in DESIGN.md; never the contract value)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-budget', type=float, default=6.0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-seed', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--dry-run', action='store_true', help='exercise launcher + rank plumbing on CPU (gloo), no GPU work, not a measurement')
     ap.add_argument('--frontend-only', action='store_true', help='time only the image front-end (BASELINE configs[1] literally: MSCKF not on the GPU)')
     args = ap.parse_args()
     if args.cpu_baseline_worker:               # child of cpu_baseline_all_cores: CPU only, exits before torch is imported
         print(json.dumps(cpu_baseline(make_config(), not args.frontend_only, budget_s=args.cpu_budget, seed=args.cpu_seed)))
-        return
+        return 0
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)           # before torch / HIP are touched in this process
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     import torch.distributed as dist
@@ -138,7 +238,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if world != args.gpus:
+        sys.stderr.write('bench.py: WORLD_SIZE=%d but --gpus %d\n' % (world, args.gpus))
+        return 2
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
@@ -154,16 +256,22 @@ def main():
     cfg = make_config()
     S, K, Wm = args.streams, args.steps, args.warmup
     with_msckf = not (args.frontend_only or args.host_images)
-    F = Wm + K + (K if with_msckf else 0)      # a second timed loop measures the front-end alone
+    PRE = PREROLL_FULL if with_msckf else PREROLL_FE
+    stagger = 0 if args.no_stagger else 1
+    PRE += stagger                              # the replicas that start one frame later reach the steady state one step later
+    F = PRE + Wm + K + (K if with_msckf else 0)  # a second timed loop measures the front-end alone
     # config/seed broadcast from rank 0 over RCCL (config broadcast, no data-path collective)
     from uav_airvision_amd import shard
     run_cfg = shard.broadcast_object({'seed': 1234, 'streams': S, 'steps': K, 'warmup': Wm} if rank == 0 else None)
     base_seed = int(run_cfg['seed'])
 
     # ---- synthetic data: U rendered streams, replicated to S streams with per-stream pixel noise ----
+    # Replica 0 of every rendered stream carries no extra noise: GPU stream 0 is exactly SyntheticStream(seed) -- the one the
+    # CPU path replays for `ate_vs_cpu_ref`.
     U = max(1, min(args.unique, S))
     t_gen = time.time()
-    streams = [SyntheticStream(cfg, seed=base_seed + 97 * rank + u, n_frames=F) for u in range(U)]
+    stream_seed0 = base_seed + 97 * rank
+    streams = [SyntheticStream(cfg, seed=stream_seed0 + u, n_frames=F) for u in range(U)]
     base0 = np.empty((U, F, H_IMG, W_IMG), np.uint8)
     base1 = np.empty((U, F, H_IMG, W_IMG), np.uint8)
     for u, st in enumerate(streams):
@@ -180,8 +288,11 @@ def main():
     for s in range(S):
         u = s % U
         for dst, src in ((img0, b0), (img1, b1)):
-            noise = torch.randint(-2, 3, (F, H_IMG, W_IMG), generator=g, device=dev, dtype=torch.int16)
-            dst[:, s] = (src[u].to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
+            if s < U:
+                dst[:, s] = src[u]
+            else:
+                noise = torch.randint(-2, 3, (F, H_IMG, W_IMG), generator=g, device=dev, dtype=torch.int16)
+                dst[:, s] = (src[u].to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
     del b0, b1
     # IMU samples per step, all streams, as flat arrays for the batched push
     imu_steps = []
@@ -200,6 +311,17 @@ def main():
                     idx.append(s); ts.append(m.timestamp); gy.append(m.angular_velocity); ac.append(m.linear_acceleration)
         imu_steps.append((np.array(idx, np.int32), np.array(ts, np.float64), np.array(gy, np.float64).reshape(-1, 3),
                           np.array(ac, np.float64).reshape(-1, 3)))
+    # The filter's copy of the IMU feed.  Staggered start: the filters of the odd replicas receive their first IMU samples one
+    # step late, so they are not yet initialised at step 0 (that frame's features are dropped, msckf.py:182-183) and start at
+    # step 1 -- from then on half of the filters run the two-camera prune on even steps and half on odd ones, the steady
+    # state of unsynchronised streams, instead of all 1024 in lock-step.  The front-end sees every sample on time.
+    imu_steps_f = list(imu_steps)
+    if stagger and F > 1:
+        late = ((imu_steps[0][0] // U) % 2) == 1
+        i0, t0_, g0, a0 = imu_steps[0]
+        i1, t1_, g1, a1 = imu_steps[1]
+        imu_steps_f[0] = (i0[~late], t0_[~late], g0[~late], a0[~late])
+        imu_steps_f[1] = (np.concatenate([i0[late], i1]), np.concatenate([t0_[late], t1_]), np.concatenate([g0[late], g1]), np.concatenate([a0[late], a1]))
     frame_ts = [[streams[s % U].frame_time(k) for s in range(S)] for k in range(F)]
     gen_s = time.time() - t_gen
 
@@ -207,9 +329,10 @@ def main():
     flt = None
     if with_msckf:
         from uav_airvision_amd.msckf_ops import BatchedMSCKF
-        flt = BatchedMSCKF(cfg, S, device=local_rank, rows_cap=4096)
+        flt = BatchedMSCKF(cfg, S, device=local_rank, rows_cap=4096, max_features=eng.max_features)
     msckf_s = [0.0]
     push_s = [0.0]
+    poses0 = []                                  # (frame index, out[S,12]) of every filter step: stream 0's row is the GPU trajectory
 
     filt_stream = torch.cuda.Stream(device=dev) if flt is not None else None
 
@@ -229,22 +352,22 @@ def main():
 
     def run_filter(k, ids_h, uv_h, n_h, queued=False):
         t1 = time.perf_counter()
-        i, t, gy, ac = imu_steps[k]
+        i, t, gy, ac = imu_steps_f[k]
         flt.push_imu(i, t, gy, ac)
         push_s[0] += time.perf_counter() - t1
         with torch.cuda.stream(filt_stream):         # the filter's kernels overlap the next frame's front-end kernels
             if queued:
-                flt.submit(ids_h, uv_h, n_h, frame_ts[k])   # the stream groups run behind their own queues ...
+                poses0.append((k, flt.submit(ids_h, uv_h, n_h, frame_ts[k])))   # the stream groups run behind their own queues ...
                 flt.wait(1)                                 # ... at most one frame ahead of the slowest group
             else:
-                flt.step(ids_h, uv_h, n_h, frame_ts[k])
+                poses0.append((k, flt.step(ids_h, uv_h, n_h, frame_ts[k])))
         msckf_s[0] += time.perf_counter() - t1
 
     def run_pipelined(k_begin, k_end):
         """Full path for frames [k_begin, k_end), organised like the reference's VIO (vio.py:24-76: image thread ->
         feature queue -> filter thread): this thread drives the front-end and hands every frame's feature message to a
         filter thread through a bounded queue, so the front-end of later frames overlaps the (host-blocking) filter step
-        of earlier ones.  The timed region ends when the last filter step has returned."""
+        of earlier ones.  The region ends when the last filter step has returned."""
         import queue, threading
         q = queue.Queue(maxsize=2)
         err = []
@@ -279,7 +402,7 @@ def main():
             th.join()
         if err:
             raise err[0]
-        flt.wait(0)                                             # the last queued step retires inside the timed region
+        flt.wait(0)                                             # the last queued step retires inside the region
 
     def run(k, filt=True):
         run_fe(k)
@@ -287,35 +410,53 @@ def main():
             ids_h, uv_h, n_h = eng.read_features_raw()
             run_filter(k, ids_h, uv_h, n_h)
 
-    for k in range(Wm):
-        run(k)
-    eng.read_features()                              # sync + overflow check of the warm-up
-    eng.enable_timing(16 * (F - Wm) + 16)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- pre-roll (un-timed, whatever --warmup says): into the steady state, with the same pipelined organisation ----
+    if flt is not None:
+        run_pipelined(0, PRE)
+    else:
+        for k in range(PRE):
+            run(k)
+    eng.read_features()                              # sync + overflow check of the pre-roll
+    c_pre = flt.counters() if flt is not None else None
+    if c_pre is not None and (c_pre['min_cam_states'] < cfg.max_cam_state_size - 2 or c_pre['prune_stream_steps'] < S):
+        sys.stderr.write('bench.py: pre-roll did not reach the steady state: %s\n' % c_pre)
+        return 3
+    # ---- the contract's W untimed warm-up steps ----
+    if flt is not None and Wm > 0:
+        run_pipelined(PRE, PRE + Wm)
+    else:
+        for k in range(PRE, PRE + Wm):
+            run(k)
+    eng.read_features()
+    c_t0 = flt.counters() if flt is not None else None
+    eng.enable_timing(16 * (F - PRE - Wm) + 16)
+
     barrier()
     msckf_s[0] = 0.0
     push_s[0] = 0.0
+    T0 = PRE + Wm
     t0 = time.perf_counter()
     if flt is not None:
-        run_pipelined(Wm, Wm + K)
+        run_pipelined(T0, T0 + K)
     else:
-        for k in range(Wm, Wm + K):
+        for k in range(T0, T0 + K):
             run(k)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed)
     timing = eng.read_timing()
+    c_t1 = flt.counters() if flt is not None else None
     fe_elapsed = None
     timing_fe = None
     if with_msckf:                                   # same engine state, next K frames, front-end only
         barrier()
         t1 = time.perf_counter()
-        for k in range(Wm + K, F):
+        for k in range(T0 + K, F):
             run(k, filt=False)
         barrier()
         fe_elapsed = shard.max_over_ranks(time.perf_counter() - t1)
@@ -351,9 +492,20 @@ def main():
                               'null-space + gate, QR-compressed update, pruning) on the published features'
                               if with_msckf else 'MSCKF not in the step (configs[1] literally)')),
                 'streams_per_gpu': S, 'unique_rendered_streams': U, 'parallelism': 'stream-sharded x%d' % world,
+                'replication': ('%d rendered streams replicated to %d per GPU with +-2 grey levels of per-stream noise; replicas of one rendered '
+                                'stream see near-identical scenes, so their work per step is near-identical' % (U, S)) +
+                               ('; the filters of the odd replicas start one step later, so half of the filters run the two-camera prune on even and half on odd steps'
+                                if stagger else '; all filters start at step 0, so all of them prune on the same steps (lock-step load)'),
                 'tracked_features_per_frame': n_t, 'published_features_per_frame': n_pub,
                 'lk_point_passes_per_frame': p_frame, 'algorithmic_bytes_per_frame': b_frame,
                 'frame_hbm_frac': fps / world * b_frame / 1e9 / HBM_PEAK_GBS,
+            },
+            'steady_state': {
+                'prerolled_frames': PRE,
+                'cam_states_at_t0': [c_t0['min_cam_states'], c_t0['max_cam_states']] if c_t0 else None,
+                'prune_steps_in_timed_region': ((c_t1['prune_stream_steps'] - c_t0['prune_stream_steps']) / float(S)) if c_t0 else None,
+                'device_buffer_reallocations_in_timed_region': (c_t1['devbuf_growths'] - c_t0['devbuf_growths']) if c_t0 else None,
+                'two_pass_streams_in_timed_region': (c_t1['two_pass_streams'] - c_t0['two_pass_streams']) if c_t0 else None,
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': 'lk_track_g16_kernel<15>',
@@ -374,13 +526,33 @@ def main():
             'frontend_only_frames_per_s': (world * S * K / fe_elapsed) if fe_elapsed else None,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(cfg, with_msckf)
+            n_traj = (T0 + K) if with_msckf else 0
+            cb = cpu_baseline(cfg, with_msckf, seed=stream_seed0, max_frames=max(400, n_traj), traj_frames=n_traj)
+            cpu_traj, truth = cb.pop('_traj', None), cb.pop('_truth', None)
+            out['cpu_baseline'] = cb
             out['cpu_baseline_all_cores'] = cpu_baseline_all_cores(with_msckf)
+            if with_msckf and cpu_traj:
+                from uav_airvision_amd.evaluate import ate
+                gpu_traj = np.array([[frame_ts[k][0]] + [float(v) for v in o[0, 2:9]] for k, o in sorted(poses0, key=lambda e: e[0]) if o[0, 0] > 0.5])
+                cpu_traj, truth = np.array(cpu_traj), np.array(truth)
+                a_gc, a_gt, a_ct = ate(gpu_traj, cpu_traj, max_dt=1e-6), ate(gpu_traj, truth, max_dt=1e-6), ate(cpu_traj, truth, max_dt=1e-6)
+                n_c = min(len(gpu_traj), len(cpu_traj))
+                out['ate_vs_cpu_ref'] = {
+                    'ate_rmse_gpu_vs_cpu_m': a_gc['rmse'], 'ate_rmse_gpu_vs_truth_m': a_gt['rmse'], 'ate_rmse_cpu_vs_truth_m': a_ct['rmse'],
+                    'relative_difference_of_ate_vs_truth': abs(a_gt['rmse'] - a_ct['rmse']) / max(a_ct['rmse'], 1e-30),
+                    'max_abs_position_difference_m': float(np.abs(gpu_traj[:n_c, 1:4] - cpu_traj[:n_c, 1:4]).max()),
+                    'frames': int(a_gc['n']),
+                    'what': 'stream 0 of the GPU batch (frames 0..%d, pre-roll included) against the CPU port of the reference path on the same '
+                            'images and IMU samples; truth = the synthetic trajectory; ATE = RMSE after SE(3) alignment '
+                            '(uav_airvision_amd/evaluate.py)' % (T0 + K - 1)}
         print(json.dumps(out))
     eng.close()
+    if flt is not None:
+        flt.close()
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -262,6 +262,11 @@ int  av_msckf_batch_submit(av_msckf_batch* b, const int64_t* ids, const double* 
 int  av_msckf_batch_wait(av_msckf_batch* b, int max_pending);
 int  av_msckf_batch_get_cov(av_msckf_batch* b, int stream_idx, double* P_host, int n, void* stream);
 int  av_msckf_batch_sizes(av_msckf_batch* b, int stream_idx, int32_t out3[3]);     /* [state dim, camera states, map features] */
+/* Run statistics over all streams (drain first): [steps, stream-steps that ran prune_cam_state_buffer (msckf.py:712-786),
+ * streams whose lost features were gated in two passes because their candidates outgrew rows_cap, device-buffer
+ * reallocations after the first step (0 in a correctly pre-sized run), min camera states, max camera states,
+ * min map features, max map features].  bench.py uses it to prove that the timed region is the steady state. */
+int  av_msckf_batch_counters(av_msckf_batch* b, int64_t out8[8]);
 
 /* Measurement hooks (bench.py's roofline leg; no reference counterpart): when enabled, every
  * launch group of av_frontend_step is bracketed by a HIP event pair ON THE STEP'S STREAM.

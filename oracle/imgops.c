@@ -27,6 +27,18 @@
  * is order-independent, which is what lets a 64-lane GPU reduction be bit-identical to this
  * scalar code.  All later float arithmetic follows OpenCV's expression order, with FP
  * contraction disabled (see oracle/Makefile).
+ *
+ * A second documented deviation -- the `err` block.  After the iterations of level 0 OpenCV's
+ * LKTrackerInvoker runs `if (status[ptidx] && err && level == 0 && (flags & LK_GET_MIN_EIGENVALS) == 0)`:
+ * it recomputes the patch difference at the FINAL position and, if that final window leaves the
+ * image (`inextPoint.x < -winSize.width || >= cols` ...), CLEARS status[ptidx].  The Python binding
+ * always passes an `err` output, so in cv2 a point that converged but whose final window is outside the
+ * image reports status 0; this restatement (which computes no err) reports 1.  The difference cannot
+ * reach the reference's results: every LK call site gates the returned points itself --
+ * feature_tracker.py:111-115 keeps only 0 <= x <= w-1, 0 <= y <= h-1 (a point inside the image has its
+ * 15x15 window within `winSize` of the image, so the err block's test passes for it), stereo_matcher.py:82-88
+ * keeps 0 <= x < w, 0 <= y < h for the forward pass, and the backward pass's status (`rev_mask`) is never
+ * read (stereo_matcher.py:70-80).  So status differs only for points the reference discards anyway.
  */
 #include <math.h>
 #include <stdint.h>

@@ -172,7 +172,8 @@ def test_batched_filters_match_reference_golden_and_oracle(cfg, groups, monkeypa
             err = max(np.abs(out[i, 2:5] - s.position).max(), np.abs(out[i, 5:9] - s.orientation).max(), np.abs(out[i, 9:12] - s.velocity).max())
             worst = max(worst, err)
             assert err < 1e-6, (k, i, err)
-        assert abs(out[0, 1] - g['t'][k]) < 1e-9 or True
+        # out[., 1] is imu_state.timestamp (msckf.py:268: the last IMU sample integrated, <= one IMU period before the frame)
+        assert 0.0 <= g['t'][k] - out[0, 1] < 0.0051
         assert np.abs(out[0, 2:5] - g['p'][k]).max() < 1e-6 and np.abs(out[0, 5:9] - g['q'][k]).max() < 1e-6
     for i in range(S):
         P, Po = bat.get_cov(i), oras[i].state_cov
@@ -217,7 +218,7 @@ def test_batched_filter_inactive_stream_and_online_reset():
                 pend[i] = next(its[i], None)
         if si:
             bat.push_imu(si, ts, gy, ac)
-        ids = np.zeros((2, 128), np.int64); uv = np.zeros((2, 128, 4)); nf = np.zeros(2, np.int32)
+        ids = np.zeros((2, 512), np.int64); uv = np.zeros((2, 512, 4)); nf = np.zeros(2, np.int32)
         for i, m in enumerate(msgs):
             nf[i] = len(m.features)
             for j, f in enumerate(m.features):
@@ -340,14 +341,14 @@ def test_queued_steps_run_ahead_and_match_the_oracle(cfg, monkeypatch):
 
 
 def test_queued_step_errors_surface_at_wait(cfg, monkeypatch):
-    """A capacity error raised inside a queued step (here: more stacked rows than rows_cap) is reported by the wait that
-    retires it, with the library's message, and the batch can still be closed."""
+    """A capacity error raised inside a queued step (here: a message capacity whose camera-pruning update cannot fit
+    rows_cap) is reported by the wait that retires it, with the library's message, and the batch can still be closed."""
     from uav_airvision_amd._native import AirvisionError
     from uav_airvision_amd.msckf_ops import BatchedMSCKF
     from uav_airvision_amd.synth import SyntheticFeatureStream
     monkeypatch.setenv('AV_MSCKF_GROUPS', '2')
     streams = [SyntheticFeatureStream(cfg, seed=71 + i, n_frames=30, n_features=100) for i in range(2)]
-    bat = BatchedMSCKF(cfg, 2, rows_cap=64)
+    bat = BatchedMSCKF(cfg, 2, rows_cap=1664)
     its = [iter(s.imu) for s in streams]
     pend = [next(it, None) for it in its]
     raised = None
@@ -360,7 +361,7 @@ def test_queued_step_errors_surface_at_wait(cfg, monkeypatch):
                 pend[i] = next(its[i], None)
         if si:
             bat.push_imu(si, ts, gy, ac)
-        ids = np.zeros((2, 128), np.int64); uv = np.zeros((2, 128, 4)); nf = np.zeros(2, np.int32)
+        ids = np.zeros((2, 512), np.int64); uv = np.zeros((2, 512, 4)); nf = np.zeros(2, np.int32)
         for i, m in enumerate(msgs):
             nf[i] = len(m.features)
             for j, f in enumerate(m.features):
@@ -423,3 +424,85 @@ def test_batched_long_run_with_feature_table_compaction(cfg):
         P, Po = bat.get_cov(i), oras[i].state_cov
         assert np.abs(P - Po).max() <= 2e-6 * np.abs(Po).max()
     bat.close()
+
+
+def test_blank_frame_drops_every_track_at_once(cfg):
+    """A blank / blurred frame: the feature message is empty, so every live track is lost in the same frame and the
+    lost-feature candidates reserve far more rows than rows_cap (here ~3-4 k against 2048).  The reference handles any
+    number (msckf.py:614-676: gate in map order, stop after > 1500 stacked rows); the batch gates such a stream first
+    and stores only the stacked features second.  Must equal the numpy oracle on every frame, before, at and after."""
+    from oracle.msckf_np import OracleMSCKF
+    from uav_airvision_amd.msckf_ops import BatchedMSCKF
+    from uav_airvision_amd.synth import SyntheticFeatureStream, feature_msg_t
+    n_frames = 48
+    streams = [SyntheticFeatureStream(cfg, seed=91, n_frames=n_frames, n_features=150),
+               SyntheticFeatureStream(cfg, seed=92, n_frames=n_frames, n_features=60)]
+    S = len(streams)
+    bat = BatchedMSCKF(cfg, S, rows_cap=2048)
+    oras = [OracleMSCKF(cfg) for _ in streams]
+    its = [iter(s.imu) for s in streams]
+    pend = [next(it, None) for it in its]
+    cap = 192
+    blank = {0: (30, 41), 1: (41,)}                      # stream 0 twice, stream 1 once (and once together with stream 0)
+    for k in range(n_frames):
+        msgs = [s.frame(k) for s in streams]
+        msgs = [feature_msg_t(m.timestamp, []) if k in blank[i] else m for i, m in enumerate(msgs)]
+        si, ts, gy, ac = [], [], [], []
+        for i, m in enumerate(msgs):
+            while pend[i] is not None and pend[i].timestamp <= m.timestamp:
+                oras[i].imu_callback(pend[i])
+                si.append(i); ts.append(pend[i].timestamp); gy.append(pend[i].angular_velocity); ac.append(pend[i].linear_acceleration)
+                pend[i] = next(its[i], None)
+        if si:
+            bat.push_imu(si, ts, gy, ac)
+        ids = np.zeros((S, cap), np.int64); uv = np.zeros((S, cap, 4)); nf = np.zeros(S, np.int32)
+        for i, m in enumerate(msgs):
+            nf[i] = len(m.features)
+            for j, f in enumerate(m.features):
+                ids[i, j] = f.id; uv[i, j] = (f.u0, f.v0, f.u1, f.v1)
+        out = bat.step(ids, uv, nf, [m.timestamp for m in msgs])
+        for i, m in enumerate(msgs):
+            r = oras[i].feature_callback(m)
+            assert (r is not None) == bool(out[i, 0])
+            n, ncam, nmap = bat.sizes(i)
+            assert (n, ncam, nmap) == (oras[i].state_cov.shape[0], len(oras[i].cam_states), len(oras[i].map_server)), (k, i)
+            s = oras[i].imu_state
+            err = max(np.abs(out[i, 2:5] - s.position).max(), np.abs(out[i, 5:9] - s.orientation).max(), np.abs(out[i, 9:12] - s.velocity).max())
+            assert err < 1e-6, (k, i, err)
+    c = bat.counters()
+    assert c['two_pass_streams'] >= 2, c                 # stream 0's blank frames really took the two-pass route
+    assert c['devbuf_growths'] == 0, c                   # nothing was reallocated after the first step's reserve
+    for i in range(S):
+        P, Po = bat.get_cov(i), oras[i].state_cov
+        assert np.abs(P - Po).max() <= 1e-6 * np.abs(Po).max()
+    bat.close()
+
+
+def test_default_trajectory_file_is_written_and_parses(dropin, cfg, tmp_path, monkeypatch):
+    """The default MSCKF(config) writes results/txts/output_<DATASET_NAME>_offset<TIME_OFFSET>.txt in append mode, one
+    line per published frame in the reference's format (msckf.py:10-16, 152-160); evaluate.load_trajectory_txt reads it
+    back and, after a second run appended to the same file, returns the last run only."""
+    dmsckf, _ = dropin
+    from uav_airvision_amd import evaluate
+    from uav_airvision_amd.synth import SyntheticFeatureStream
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv('DATASET_NAME', 'SYN_07')
+    monkeypatch.setenv('TIME_OFFSET', '40')
+    fs = SyntheticFeatureStream(cfg, seed=5, n_frames=30, n_features=60)
+    runs = []
+    for _ in range(2):
+        flt = dmsckf.MSCKF(cfg)                          # write_trajectory defaults to True
+        poses = []
+        _drive(flt, fs, lambda r: poses.append(None if r is None else (flt.state_server.imu_state.timestamp, flt.state_server.imu_state.position.copy(),
+                                                                       flt.state_server.imu_state.orientation.copy())))
+        flt.close()
+        runs.append([p for p in poses if p is not None])
+    path = tmp_path / 'results' / 'txts' / 'output_SYN_07_offset40.txt'
+    assert path.exists()
+    raw = [l for l in open(path).read().splitlines() if l.strip()]
+    assert len(raw) == len(runs[0]) + len(runs[1]) and len(runs[0]) == 30
+    assert all(len(l.split()) == 8 for l in raw)
+    tr = evaluate.load_trajectory_txt(str(path))
+    assert tr.shape == (30, 8)                           # the concatenated first run is dropped at the backwards time jump
+    for row, (t, p, q) in zip(tr, runs[1]):
+        assert abs(row[0] - t) < 1e-6 and np.abs(row[1:4] - p).max() < 1e-9 and np.abs(row[4:8] - q).max() < 1e-9

@@ -59,3 +59,33 @@ def test_two_rank_gloo_sharding():
     assert tot0 == tot1 == [5.0, 10.0]
     assert all0 == all1 and sorted(all0) == [0, 1, 2, 3, 4]
     assert all0[4] == ((7, 8), 81.0) and k0 == k1 == [0.0, 1.0, 2.0, 3.0]
+
+
+def test_bench_self_launches_its_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent starts one child per rank before anything touches
+    a GPU, the ranks broadcast the run configuration, partition the streams, take the max-over-ranks time and the
+    sum-over-ranks counters, and exactly ONE JSON line comes out (rank 0's).  --dry-run: gloo on CPU, no GPU work."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '4', '--warmup', '1', '--streams', '6'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d['dry_run'] is True and d['n_gpus'] == 2 and d['steps'] == 4 and d['warmup'] == 1 and d['scaling'] == 'weak'
+    assert d['config']['streams_per_gpu'] == 6 and d['config']['streams_total'] == 12 and d['config']['seed'] == 1234
+    # rank r sleeps (1 + r) ms per step: the reported time is the slower rank's
+    assert d['ms_per_step'] >= 2.0
+    assert abs(d['value'] - 12 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
+
+
+def test_bench_reports_a_failed_rank():
+    """A rank that dies makes the self-launching parent exit non-zero (here: --gpus 2 under a WORLD_SIZE=3 mismatch is
+    rejected by every rank before any GPU call)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE='3', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and 'WORLD_SIZE=3' in p.stderr and not p.stdout.strip()

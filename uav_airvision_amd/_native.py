@@ -90,6 +90,7 @@ SIGNATURES = {
     'av_msckf_batch_wait': (C.c_int, [_P, C.c_int]),
     'av_msckf_batch_get_cov': (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     'av_msckf_batch_sizes': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32 * 3)]),
+    'av_msckf_batch_counters': (C.c_int, [_P, C.POINTER(C.c_int64 * 8)]),
     'av_frontend_enable_timing': (C.c_int, [_P, C.c_int]),
     'av_frontend_read_timing': (C.c_int, [_P, C.POINTER(C.c_double * 4), C.POINTER(C.c_int32 * 4)]),
 }

@@ -508,19 +508,21 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
     }
     if (a.prof && slot == 0 && tid == 0) a.prof[3] = __builtin_amdgcn_s_memrealtime();
     // rows 3..R4-1 of H and r are A^T H_x and A^T r.  Write them out (dense row of width ld).
-    const int row0 = a.row_off[f];
-    if (a.zero_fill) {
-        for (int i = tid; i < K * a.ld; i += TEAM) {
-            const int rI = i / a.ld, c = i - rI * a.ld;
-            Hout[(size_t)(row0 + rI) * a.ld + c] = 0.0;
+    const int row0 = a.row_off[f];                 // < 0: gate only, nothing is stored (two-pass streams, msckf_batch.inc)
+    if (row0 >= 0) {
+        if (a.zero_fill) {
+            for (int i = tid; i < K * a.ld; i += TEAM) {
+                const int rI = i / a.ld, c = i - rI * a.ld;
+                Hout[(size_t)(row0 + rI) * a.ld + c] = 0.0;
+            }
+            team_sync<TEAM>();
         }
-        team_sync<TEAM>();
+        for (int i = tid; i < K * C6; i += TEAM) {
+            const int rI = i / C6, c = i - rI * C6;
+            Hout[(size_t)(row0 + rI) * a.ld + IMU_DIM + 6 * cidx[c / 6] + c % 6] = H[(3 + rI) * C6 + c];
+        }
+        for (int i = tid; i < K; i += TEAM) rout[row0 + i] = rr[3 + i];
     }
-    for (int i = tid; i < K * C6; i += TEAM) {
-        const int rI = i / C6, c = i - rI * C6;
-        Hout[(size_t)(row0 + rI) * a.ld + IMU_DIM + 6 * cidx[c / 6] + c % 6] = H[(3 + rI) * C6 + c];
-    }
-    for (int i = tid; i < K; i += TEAM) rout[row0 + i] = rr[3 + i];
 
     if (a.prof && slot == 0 && tid == 0) a.prof[4] = __builtin_amdgcn_s_memrealtime();
     // ---- gating test (msckf.py:604-612): S = H' Psub H'^T + s^2 I = (Q^T G Q)[3:, 3:] + s^2 I, gamma = r'^T S^-1 r' ----

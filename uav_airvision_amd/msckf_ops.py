@@ -152,7 +152,13 @@ class BatchedMSCKF(object):
     library, one batched launch per numeric phase.  Mirrors MSCKF.imu_callback / feature_callback
     (reference: src/msckf.py:162-228) for many streams at once."""
 
-    def __init__(self, config, n_streams, device=0, rows_cap=8192):
+    def __init__(self, config, n_streams, device=0, rows_cap=None, max_features=None):
+        """rows_cap: rows of the per-stream block buffer; by default sized from `max_features` (features per message:
+        the camera-pruning update stacks 5 rows per feature, the lost-feature update at most 1500 + one block)."""
+        if max_features is None:
+            max_features = int(config.grid_row) * int(config.grid_col) * int(config.grid_max_feature_num)
+        rows_cap = max(2048, 5 * int(max_features) + 64) if rows_cap is None else int(rows_cap)
+        self.rows_cap = rows_cap
         self.config = config
         self.S = int(n_streams)
         self.device = int(device)
@@ -236,6 +242,16 @@ class BatchedMSCKF(object):
         o = (C.c_int32 * 3)()
         N.check(N.lib().av_msckf_batch_sizes(self._h, int(s), C.byref(o)))
         return int(o[0]), int(o[1]), int(o[2])
+
+    COUNTER_NAMES = ('steps', 'prune_stream_steps', 'two_pass_streams', 'devbuf_growths', 'min_cam_states', 'max_cam_states',
+                     'min_map_features', 'max_map_features')
+
+    def counters(self):
+        """Run statistics over all streams (av_msckf_batch_counters); drains the queue first."""
+        self.wait(0)
+        o = (C.c_int64 * 8)()
+        N.check(N.lib().av_msckf_batch_counters(self._h, C.byref(o)))
+        return dict(zip(self.COUNTER_NAMES, [int(v) for v in o]))
 
     def get_cov(self, s):
         n = self.sizes(s)[0]
