@@ -247,7 +247,13 @@ void av_msckf_batch_destroy(av_msckf_batch* b);
 /* MSCKF.imu_callback for n samples (msckf.py:162-175 incl. initialize_gravity_and_bias); gyro/acc are [n][3]. */
 int  av_msckf_batch_push_imu(av_msckf_batch* b, const int32_t* stream_idx, const double* timestamps, const double* gyro, const double* acc, int n);
 /* MSCKF.feature_callback for every stream.  Host inputs: stream s has n_feat[s] features, ids[s*cap+k],
- * uv[(s*cap+k)*4..] = u0 v0 u1 v1.  out[s*12..] = {published (0/1), t, p[3], q[4] (JPL xyzw), v[3]}. */
+ * uv[(s*cap+k)*4..] = u0 v0 u1 v1.  out[s*12..] = {published (0/1), t, p[3], q[4] (JPL xyzw), v[3]}.
+ * A stream is live for a frame iff its gravity initialisation was completed by an IMU sample not newer than the frame
+ * (msckf.py:182-183 under the deterministic replay); timestamps[s] < 0 means "no frame for stream s in this
+ * step" (sequences of different lengths stepped together): the stream idles and reports published = 0.
+ * The first step fixes the message capacity `cap` the device buffers are sized for; rows_cap must be >= 5*cap
+ * (camera-pruning update) and >= 1664 (lost-feature update: 1500-row cut + one block), else AV_E_CAPACITY;
+ * rows_cap = 0 at create sizes the block buffers from that first `cap` (max(2048, 5*cap + 64) rows). */
 int  av_msckf_batch_step(av_msckf_batch* b, const int64_t* ids, const double* uv, const int32_t* n_feat, int cap,
                          const double* timestamps, double* out, void* stream);
 /* The same step, queued: returns at once; the stream groups of the batch consume their queues independently (a group

@@ -110,3 +110,39 @@ def replay(dataset, imu_sinks, on_stereo, max_frames=None):
         if max_frames is not None and n >= max_frames:
             break
     return n
+
+
+def write_euroc_layout(root, stream, groundtruth_rate_hz=200.0, frame_range=None, write_csv=True):
+    """Write a seeded synthetic stream (uav_airvision_amd.synth.SyntheticStream) as an EuRoC-layout directory
+    `root/mav0/{cam0,cam1}/data/<ns>.png`, `imu0/data.csv`, `state_groundtruth_estimate0/data.csv`, so that the same
+    reader / replay / sweep code that runs on the real dataset (which is not redistributable and not present on the build
+    or GPU boxes) can be exercised end to end.  PNG is lossless: the reader returns the rendered pixels bit for bit.
+    Ground truth = the analytic trajectory of the stream (position of the IMU frame; identity orientation columns).
+    `frame_range=(a, b)` writes only the images of frames a..b-1 (several writer processes can share one sequence);
+    `write_csv=False` skips the IMU / ground-truth files."""
+    from PIL import Image
+    for cam in ('cam0', 'cam1'):
+        os.makedirs(os.path.join(root, 'mav0', cam, 'data'), exist_ok=True)
+    a, b = (0, stream.n_frames) if frame_range is None else frame_range
+    for k in range(a, b):
+        m = stream.frame(k)
+        name = '%d.png' % int(round(m.timestamp * 1e9))
+        Image.fromarray(m.cam0_image).save(os.path.join(root, 'mav0', 'cam0', 'data', name))
+        Image.fromarray(m.cam1_image).save(os.path.join(root, 'mav0', 'cam1', 'data', name))
+    if not write_csv:
+        return root
+    os.makedirs(os.path.join(root, 'mav0', 'imu0'), exist_ok=True)
+    with open(os.path.join(root, 'mav0', 'imu0', 'data.csv'), 'w') as f:
+        f.write('#timestamp [ns],w_RS_S_x [rad s^-1],w_RS_S_y [rad s^-1],w_RS_S_z [rad s^-1],a_RS_S_x [m s^-2],a_RS_S_y [m s^-2],a_RS_S_z [m s^-2]\n')
+        for m in stream.imu:
+            f.write('%d,%.12f,%.12f,%.12f,%.12f,%.12f,%.12f\n' % (int(round(m.timestamp * 1e9)), *m.angular_velocity, *m.linear_acceleration))
+    os.makedirs(os.path.join(root, 'mav0', 'state_groundtruth_estimate0'), exist_ok=True)
+    with open(os.path.join(root, 'mav0', 'state_groundtruth_estimate0', 'data.csv'), 'w') as f:
+        f.write('#timestamp,p_RS_R_x [m],p_RS_R_y [m],p_RS_R_z [m],q_RS_w [],q_RS_x [],q_RS_y [],q_RS_z [],v_RS_R_x,v_RS_R_y,v_RS_R_z,bw_x,bw_y,bw_z,ba_x,ba_y,ba_z\n')
+        t_begin, t_end = stream.imu[0].timestamp, stream.imu[-1].timestamp
+        n = int((t_end - t_begin) * groundtruth_rate_hz) + 1
+        for i in range(n):
+            t = t_begin + i / groundtruth_rate_hz
+            p = stream.position(t)
+            f.write(','.join(['%d' % int(round(t * 1e9))] + ['%.9f' % v for v in p] + ['1', '0', '0', '0'] + ['0'] * 9) + '\n')
+    return root

@@ -153,12 +153,12 @@ class BatchedMSCKF(object):
     (reference: src/msckf.py:162-228) for many streams at once."""
 
     def __init__(self, config, n_streams, device=0, rows_cap=None, max_features=None):
-        """rows_cap: rows of the per-stream block buffer; by default sized from `max_features` (features per message:
-        the camera-pruning update stacks 5 rows per feature, the lost-feature update at most 1500 + one block)."""
-        if max_features is None:
-            max_features = int(config.grid_row) * int(config.grid_col) * int(config.grid_max_feature_num)
-        rows_cap = max(2048, 5 * int(max_features) + 64) if rows_cap is None else int(rows_cap)
-        self.rows_cap = rows_cap
+        """rows_cap: rows of the per-stream block buffer.  None = sized by the library from the capacity of the first
+        feature message (the camera-pruning update stacks 5 rows per feature, the lost-feature update at most 1500 + one
+        block); `max_features`, when given, sizes it up front instead."""
+        if rows_cap is None:
+            rows_cap = 0 if max_features is None else max(2048, 5 * int(max_features) + 64)
+        self.rows_cap = int(rows_cap)
         self.config = config
         self.S = int(n_streams)
         self.device = int(device)

@@ -1,11 +1,17 @@
-"""Sequence x offset sweep runner: the reference's `run.bat:4-12` (9 sequences x
-7 offsets, run serially through `main.py --path DIR --offset S`) as a sharded job: every (sequence,
-offset) pair is one independent stream, pairs are partitioned over ranks with `shard.partition`, each
-rank runs its pairs through the drop-in `ImageProcessor` + `MSCKF` on its GPU with the deterministic
-replay, and trajectories are gathered at the end (no per-frame communication).
+"""Sequence x offset sweep runner on the batched throughput path.
+
+The reference's `run.bat:4-12` runs 9 sequences x 7 start offsets serially through `main.py --path DIR --offset S`
+(`main.py:10-34`, `streaming/dataset.py:189-214`).  Here every (sequence, offset) pair is one independent stream; the
+pairs are partitioned over ranks (`shard.partition`, one process per GPU) and each rank steps ALL of its streams
+together: one `FrontendEngine(n_streams=k)` (one batched kernel launch per stage and step for the k streams) feeding one
+`BatchedMSCKF(k)` -- the same two objects bench.py times -- driven by the deterministic replay of SURVEY 3.5 (IMU
+messages with timestamp <= t before the frame at t).  Sequences end at different frames; a finished stream idles
+(blank images, frame timestamp -1 for the filter) until the longest one is done.  Trajectories are gathered at the end
+(`shard.gather_trajectories`); there is no per-frame communication.
 
     python -m uav_airvision_amd.sweep --root /data/euroc --sequences MH_01_easy MH_03_medium --offsets 0 10 20
     python -m torch.distributed.run --nproc-per-node 8 -m uav_airvision_amd.sweep ...
+    python -m uav_airvision_amd.sweep --make-synthetic /tmp/syn --sequences SYN_01 SYN_02 --frames 200 ...   (no dataset at hand)
 """
 import argparse
 import json
@@ -16,8 +22,9 @@ import numpy as np
 
 
 def run_stream(config, dataset_path, offset, device=0, max_frames=None):
-    """One (sequence, offset) stream through the GPU hot path; returns float64[n, 8] trajectory
-    (t px py pz qx qy qz qw: the reference's output line, msckf.py:152-158)."""
+    """ONE (sequence, offset) stream through the single-stream drop-in classes (`ImageProcessor` + `MSCKF`, the objects
+    `modules/vio.py` constructs); returns (float64[n, 8] trajectory `t px py pz qx qy qz qw`, dataset).  The sweep itself
+    uses `run_batched`; this is the reference-shaped path kept for comparison and for `vio.py`-style callers."""
     here = os.path.dirname(os.path.abspath(__file__))
     dropin = os.path.join(here, 'dropin')
     if dropin not in sys.path:
@@ -41,12 +48,115 @@ def run_stream(config, dataset_path, offset, device=0, max_frames=None):
     return np.array(traj, dtype=np.float64).reshape(-1, 8), ds
 
 
+class BatchedRunner(object):
+    """k streams stepped together on one GPU: `FrontendEngine(n_streams=k)` -> `BatchedMSCKF(k)`.
+
+    `datasets`: objects with `.imu` and `.stereo` iterables of the reference's message namedtuples
+    (`euroc.EuRoCDataset` after `set_starttime`, or anything shaped like it).  `run()` returns one float64[n, 8]
+    trajectory per stream in the reference's output-line layout (msckf.py:152-158: t = imu_state.timestamp).
+    `on_step(step, timestamps, ids, uv, n_feat, out)` -- optional, called once per step with the published feature
+    arrays of the front-end and the filter's float64[k, 12] output of the same step (parity tests); without it the
+    filter runs one step behind the front-end (queued), the way bench.py pipelines them."""
+
+    def __init__(self, config, n_streams, device=0, rows_cap=None):
+        from .frontend import FrontendEngine
+        from .msckf_ops import BatchedMSCKF
+        self.config, self.S, self.device = config, int(n_streams), int(device)
+        self.eng = FrontendEngine(config, n_streams=self.S, device=self.device)
+        self.flt = BatchedMSCKF(config, self.S, device=self.device, rows_cap=rows_cap, max_features=self.eng.max_features)
+        self.frames_done = np.zeros(self.S, np.int64)
+
+    def close(self):
+        self.eng.close(); self.flt.close()
+
+    def run(self, datasets, max_frames=None, on_step=None):
+        S = self.S
+        assert len(datasets) == S
+        eng, flt = self.eng, self.flt
+        its_img = [iter(d.stereo) for d in datasets]
+        its_imu = [iter(d.imu) for d in datasets]
+        pend = [next(it, None) for it in its_imu]
+        img0 = np.zeros((S, eng.height, eng.width), np.uint8)
+        img1 = np.zeros_like(img0)
+        traj = [[] for _ in range(S)]
+        last_t = np.zeros(S)
+        inflight = []                                     # outputs of submitted steps that have not been recorded yet
+
+        def record(out):
+            for s in range(S):
+                if out[s, 0] > 0.5:
+                    traj[s].append(out[s, 1:9].copy())
+
+        step = 0
+        while True:
+            msgs = [next(it, None) for it in its_img] if (max_frames is None or step < max_frames) else [None] * S
+            if all(m is None for m in msgs):
+                break
+            ts_f = np.full(S, -1.0)                       # the filter's frame times: < 0 = no frame for this stream
+            ts_e = np.empty(S)
+            idx, tt, gy, ac = [], [], [], []
+            for s, m in enumerate(msgs):
+                if m is None:                             # finished: idles on blank images until the longest stream ends
+                    its_img[s] = iter(())
+                    img0[s] = 0; img1[s] = 0
+                    last_t[s] += 0.05
+                    ts_e[s] = last_t[s]
+                    continue
+                ts_f[s] = ts_e[s] = last_t[s] = m.timestamp
+                img0[s] = m.cam0_image; img1[s] = m.cam1_image
+                self.frames_done[s] += 1
+                while pend[s] is not None and pend[s].timestamp <= m.timestamp:      # SURVEY 3.5 / vio.py:43-44
+                    idx.append(s); tt.append(pend[s].timestamp); gy.append(pend[s].angular_velocity); ac.append(pend[s].linear_acceleration)
+                    pend[s] = next(its_imu[s], None)
+            if idx:
+                eng.push_imu_batch(np.array(idx, np.int32), np.array(tt), np.array(gy).reshape(-1, 3))
+                flt.push_imu(idx, tt, gy, ac)
+            eng.step_host(img0, img1, ts_e)
+            eng.read_features_begin(step & 1)
+            ids, uv, n = eng.read_features_end(step & 1)
+            n[ts_f < 0] = 0
+            if on_step is not None:
+                out = flt.step(ids, uv, n, ts_f)
+                record(out)
+                on_step(step, ts_f, ids, uv, n, out)
+            else:
+                inflight.append(flt.submit(ids, uv, n, ts_f))
+                flt.wait(1)                               # at most one step behind: the next frames are decoded meanwhile
+                while len(inflight) > 1:
+                    record(inflight.pop(0))
+            step += 1
+        flt.wait(0)
+        for out in inflight:
+            record(out)
+        return [np.array(t, dtype=np.float64).reshape(-1, 8) for t in traj]
+
+
+def run_batched(config, dataset_paths, offsets, device=0, max_frames=None, on_step=None, rows_cap=None):
+    """Open (path, offset) pairs as EuRoC datasets and run them as one batch; returns (trajectories, datasets)."""
+    from .euroc import EuRoCDataset
+    dss = []
+    for p, o in zip(dataset_paths, offsets):
+        ds = EuRoCDataset(p)
+        ds.set_starttime(o)
+        dss.append(ds)
+    r = BatchedRunner(config, len(dss), device=device, rows_cap=rows_cap)
+    try:
+        trajs = r.run(dss, max_frames=max_frames, on_step=on_step)
+    finally:
+        r.close()
+    return trajs, dss
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument('--root', required=True, help='directory holding the EuRoC sequences')
+    ap.add_argument('--root', help='directory holding the EuRoC sequences')
+    ap.add_argument('--make-synthetic', metavar='DIR', help='first write EuRoC-layout synthetic sequences (one per --sequences name) into DIR and use it as --root')
+    ap.add_argument('--frames', type=int, default=200, help='frames per synthetic sequence (--make-synthetic)')
     ap.add_argument('--sequences', nargs='+', required=True)
     ap.add_argument('--offsets', nargs='+', type=float, default=[0.0])
     ap.add_argument('--max-frames', type=int, default=None)
+    ap.add_argument('--batch', type=int, default=64, help='streams stepped together per GPU (larger sweeps run in several batches)')
+    ap.add_argument('--grid', nargs=3, type=int, default=None, metavar=('ROWS', 'COLS', 'MAX'), help='feature grid (default 4 5 5; 10 15 10 = the 1500-feature sweep)')
     ap.add_argument('--out', default='results/txts')
     args = ap.parse_args(argv)
 
@@ -62,18 +172,32 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    cfg = ConfigEuRoC(grid_row=args.grid[0], grid_col=args.grid[1], grid_max_feature_num=args.grid[2]) if args.grid else ConfigEuRoC()
+    root = args.root
+    if args.make_synthetic:
+        root = args.make_synthetic
+        if rank == 0:
+            from .euroc import write_euroc_layout
+            from .synth import SyntheticStream
+            for i, seq in enumerate(args.sequences):
+                if not os.path.isdir(os.path.join(root, seq, 'mav0')):
+                    write_euroc_layout(os.path.join(root, seq), SyntheticStream(cfg, seed=1000 + i, n_frames=args.frames, motion_scale=1.5, t0=1403636580.0 + 1000 * i, rest=1.0))
+        if world > 1:
+            dist.barrier()
+    if not root:
+        ap.error('--root or --make-synthetic is required')
     jobs = shard.broadcast_object([(s, o) for s in args.sequences for o in args.offsets] if rank == 0 else None)
-    cfg = ConfigEuRoC()
     mine = shard.partition(len(jobs), world, rank)
     local_traj, report = {}, {}
-    for j in mine:
-        seq, off = jobs[j]
-        traj, ds = run_stream(cfg, os.path.join(args.root, seq), off, device=local, max_frames=args.max_frames)
-        local_traj[j] = traj
-        gt = ds.groundtruth_array()
-        if len(gt) and len(traj) > 20:
-            a, r = ate(traj, gt), rte(traj, gt)
-            report[j] = dict(sequence=seq, offset=off, frames=len(traj), ate_rmse=a['rmse'], ate_mean=a['mean'], rte_rmse=r['rmse'])
+    for b0 in range(0, len(mine), args.batch):
+        chunk = mine[b0:b0 + args.batch]
+        trajs, dss = run_batched(cfg, [os.path.join(root, jobs[j][0]) for j in chunk], [jobs[j][1] for j in chunk], device=local, max_frames=args.max_frames)
+        for j, traj, ds in zip(chunk, trajs, dss):
+            local_traj[j] = traj
+            gt = ds.groundtruth_array()
+            if len(gt) and len(traj) > 20:
+                a, r = ate(traj, gt), rte(traj, gt)
+                report[j] = dict(sequence=jobs[j][0], offset=jobs[j][1], frames=len(traj), ate_rmse=a['rmse'], ate_mean=a['mean'], rte_rmse=r['rmse'])
     allt = shard.gather_trajectories(local_traj, len(jobs), world, rank)
     if rank == 0:
         os.makedirs(args.out, exist_ok=True)

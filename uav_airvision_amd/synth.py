@@ -88,12 +88,13 @@ class SyntheticStream(object):
     """
 
     def __init__(self, config, seed=0, n_frames=20, t0=100.0, lead_in=1.0, motion_scale=1.0,
-                 pixel_noise=1.0, texture=None, render=True):
+                 pixel_noise=1.0, texture=None, render=True, rest=0.0):
         self.config = config
         self.seed = int(seed)
         self.n_frames = int(n_frames)
         self.t0 = float(t0)
         self.lead_in = float(lead_in)
+        self.rest = float(rest)                 # seconds of standstill after frame 0 (EuRoC sequences start at rest on the ground)
         self.motion_scale = float(motion_scale)
         self.pixel_noise = float(pixel_noise)
         self.rng = np.random.default_rng(0xA1B0 + self.seed)
@@ -122,12 +123,12 @@ class SyntheticStream(object):
         return t * t / (t + 1.0)
 
     def position(self, t):
-        s = self._s(t - self.t0) * 1.0
+        s = self._s(t - self.t0 - self.rest) * 1.0
         m = self.motion_scale
         return m * np.array([0.5 * np.sin(0.5 * s), 0.3 * np.sin(0.7 * s), 0.1 * np.sin(0.3 * s)])
 
     def R_i_w(self, t):
-        s = self._s(t - self.t0)
+        s = self._s(t - self.t0 - self.rest)
         m = self.motion_scale
         th = m * np.array([0.05 * np.sin(0.4 * s), 0.04 * np.sin(0.6 * s), 0.06 * np.sin(0.5 * s)])
         return self.R_i_w0 @ _so3_exp(th)
