@@ -443,7 +443,10 @@ def test_blank_frame_drops_every_track_at_once(cfg):
     its = [iter(s.imu) for s in streams]
     pend = [next(it, None) for it in its]
     cap = 192
-    blank = {0: (30, 41), 1: (41,)}                      # stream 0 twice, stream 1 once (and once together with stream 0)
+    # before the first camera pruning (frame 19) the tracks are long: stream 0's 130 candidates reserve ~5.5 k rows at frame
+    # 17, stream 1's 58 candidates ~2.7 k at frame 18, against rows_cap 2048; a later blank frame (41: tracks shortened by
+    # the pruning, no candidate with >= 3 observations) takes the ordinary route
+    blank = {0: (17, 41), 1: (18, 41)}
     for k in range(n_frames):
         msgs = [s.frame(k) for s in streams]
         msgs = [feature_msg_t(m.timestamp, []) if k in blank[i] else m for i, m in enumerate(msgs)]

@@ -83,15 +83,18 @@ __device__ __forceinline__ int dot2_keep(uint32_t a, uint32_t b, int c)
 }
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
 
-constexpr int TILE = 32;          // staged tile: 32 rows x 32 bytes
-constexpr int TPITCH = 36;        // LDS row pitch in bytes (9 dwords: spreads rows over banks)
-constexpr int TILE_DWORDS = TILE * TPITCH / 4;
+constexpr int TILE_ROWS = 24;     // staged J tile: 24 rows x 32 bytes (window 16 rows + 4 px of drift either way)
+constexpr int TILE_COLS = 32;
+constexpr int TPITCH = 36;        // LDS row pitch in bytes (9 dwords: the 16 rows of a point fall on 16 different banks)
+constexpr int TILE_DWORDS = 240;  // >= 24 * 9, and == 16 mod 32: the two points of a 32-lane LDS access group use disjoint banks
 
 // =================================================================================================
-// 16 lanes per point: lane r of a DPP row owns window row r (15 pixels); one wavefront tracks 4 points.
-// Per Newton iteration the pixel work per lane is 15 x (2 perm + 2 dot2 + shift + sub + 2 mad) while the
-// float update of the point (weights, 2x2 solve, stop tests), which is identical for every lane of a point,
-// is now shared by four points per instruction instead of one.  Window sums stay exact: int32 per lane
+// 16 lanes per point: lane r of a DPP row owns window row r (15 pixels + the column right of them); lane 15 owns
+// row 15, which only feeds the bilinear interpolation of row 14.  A lane builds ONLY its own row of the I patch
+// and of the two Scharr derivative patches; the row below, which every bilinear sample needs, is read out of the
+// next lane's registers by the DPP operand of v_dot2c_i32_i16 (row_shl:1) -- no second copy of the row, no
+// v_mov_dpp, no second byte permute per pixel.  The float Newton update of a point is identical in all its
+// lanes, so one VALU instruction serves 4 points.  Window sums stay exact: int32 per lane
 // (15 x 8160 x 4080 < 2^31), split into 16-bit halves for the 16-lane DPP butterfly, recombined in fp64.
 // =================================================================================================
 typedef unsigned short av_v2u __attribute__((ext_vector_type(2)));
@@ -114,8 +117,117 @@ __device__ __forceinline__ double row_sum16_exact(int v)
     return (double)hi * 65536.0 + (double)lo;
 }
 
-template <int WIN>
-__global__ __launch_bounds__(256) void lk_track_g16_kernel(LKArgs a)
+// Bilinear sample of five packed pixel (or derivative) pairs x_i = (v[c], v[c+1]) of this lane's row with the same
+// pairs of the row below (next lane, DPP row_shl:1):  o_i = (x_i . wtop + below(x_i) . wbot + rnd) >> SH.
+// One asm statement, for two reasons: the compiler does not fold a DPP move into v_dot2c (it has a tied accumulator),
+// and its hazard recogniser does not see into inline asm -- a DPP operand written by a VALU instruction needs 2 wait
+// states, guaranteed here by issuing the five plain dot products first.
+template <int SH>
+__device__ __forceinline__ void bilin5(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t wtop, uint32_t wbot, int rnd,
+                                       int& o0, int& o1, int& o2, int& o3, int& o4)
+{
+    asm("v_dot2_i32_i16 %0, %5, %10, %12\n\t"
+        "v_dot2_i32_i16 %1, %6, %10, %12\n\t"
+        "v_dot2_i32_i16 %2, %7, %10, %12\n\t"
+        "v_dot2_i32_i16 %3, %8, %10, %12\n\t"
+        "v_dot2_i32_i16 %4, %9, %10, %12\n\t"
+        "v_dot2c_i32_i16_dpp %0, %5, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_dot2c_i32_i16_dpp %1, %6, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_dot2c_i32_i16_dpp %2, %7, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_dot2c_i32_i16_dpp %3, %8, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_dot2c_i32_i16_dpp %4, %9, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_ashrrev_i32 %0, %13, %0\n\t"
+        "v_ashrrev_i32 %1, %13, %1\n\t"
+        "v_ashrrev_i32 %2, %13, %2\n\t"
+        "v_ashrrev_i32 %3, %13, %3\n\t"
+        "v_ashrrev_i32 %4, %13, %4"
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(wtop), "v"(wbot), "v"(rnd), "n"(SH));
+}
+
+// The I patch itself is only ever used as the accumulator seed of the iteration's interpolation:
+//   ((dot + R) >> 9) - ival == (dot + R - (ival << 9)) >> 9,  seed = R - (ival << 9),  ival << 9 == acc & ~511 (acc >= 0)
+__device__ __forceinline__ void bilin5_seed(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t wtop, uint32_t wbot, int rnd,
+                                            int& o0, int& o1, int& o2, int& o3, int& o4)
+{
+    asm("v_dot2_i32_i16 %0, %5, %10, %12\n\t"
+        "v_dot2_i32_i16 %1, %6, %10, %12\n\t"
+        "v_dot2_i32_i16 %2, %7, %10, %12\n\t"
+        "v_dot2_i32_i16 %3, %8, %10, %12\n\t"
+        "v_dot2_i32_i16 %4, %9, %10, %12\n\t"
+        "v_dot2c_i32_i16_dpp %0, %5, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_dot2c_i32_i16_dpp %1, %6, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_dot2c_i32_i16_dpp %2, %7, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_dot2c_i32_i16_dpp %3, %8, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_dot2c_i32_i16_dpp %4, %9, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_and_b32 %0, 0xfffffe00, %0\n\t"
+        "v_and_b32 %1, 0xfffffe00, %1\n\t"
+        "v_and_b32 %2, 0xfffffe00, %2\n\t"
+        "v_and_b32 %3, 0xfffffe00, %3\n\t"
+        "v_and_b32 %4, 0xfffffe00, %4\n\t"
+        "v_sub_u32 %0, 0x100, %0\n\t"
+        "v_sub_u32 %1, 0x100, %1\n\t"
+        "v_sub_u32 %2, 0x100, %2\n\t"
+        "v_sub_u32 %3, 0x100, %3\n\t"
+        "v_sub_u32 %4, 0x100, %4"
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(wtop), "v"(wbot), "v"(rnd));
+}
+
+// a * b + c on the low 24 bits of a and b, ONE instruction (left to itself the compiler turns `c += __mul24(a, b)` chains into
+// v_mul_i32_i24 + v_add3_u32 plus a sign-extension v_bfe per operand: 1.5 - 2x the instructions of the window loops)
+__device__ __forceinline__ int mad24(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// The Newton iteration's version for five window columns c0..c0+4 of this lane's J row (16 bytes in T0..T3): byte pairs by
+// v_perm, then as above with a per-column accumulator seed (rounding term minus the I sample):
+//   d_i = ((J[c], J[c+1]) . wtop + below(...) . wbot + seed_i) >> 9
+template <int C0>
+__device__ __forceinline__ void jdiff5(uint32_t T0, uint32_t T1, uint32_t T2, uint32_t T3, uint32_t sel0, uint32_t sel1, uint32_t sel2, uint32_t sel3,
+                                       uint32_t wtop, uint32_t wbot, int s0, int s1, int s2, int s3, int s4,
+                                       int& d0, int& d1, int& d2, int& d3, int& d4)
+{
+    // column c reads bytes (c, c+1): dword q = c >> 2, byte o = c & 3; o == 3 takes byte 0 of the next dword
+    uint32_t p0, p1, p2, p3, p4;
+#define AV_TQ(c) (((c) >> 2) == 0 ? T0 : ((c) >> 2) == 1 ? T1 : ((c) >> 2) == 2 ? T2 : T3)
+#define AV_TN(c) (((c) >> 2) == 0 ? T1 : ((c) >> 2) == 1 ? T2 : T3)         /* never needed for c >> 2 == 3 (bytes 12..15 only) */
+#define AV_SL(c) (((c) & 3) == 0 ? sel0 : ((c) & 3) == 1 ? sel1 : ((c) & 3) == 2 ? sel2 : sel3)
+    asm("v_perm_b32 %5, %10, %11, %20\n\t"
+        "v_perm_b32 %6, %12, %13, %21\n\t"
+        "v_perm_b32 %7, %14, %15, %22\n\t"
+        "v_perm_b32 %8, %16, %17, %23\n\t"
+        "v_perm_b32 %9, %18, %19, %24\n\t"
+        "v_dot2_i32_i16 %0, %5, %25, %27\n\t"
+        "v_dot2_i32_i16 %1, %6, %25, %28\n\t"
+        "v_dot2_i32_i16 %2, %7, %25, %29\n\t"
+        "v_dot2_i32_i16 %3, %8, %25, %30\n\t"
+        "v_dot2_i32_i16 %4, %9, %25, %31\n\t"
+        "v_dot2c_i32_i16_dpp %0, %5, %26 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_dot2c_i32_i16_dpp %1, %6, %26 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_dot2c_i32_i16_dpp %2, %7, %26 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_dot2c_i32_i16_dpp %3, %8, %26 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_dot2c_i32_i16_dpp %4, %9, %26 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_ashrrev_i32 %0, 9, %0\n\t"
+        "v_ashrrev_i32 %1, 9, %1\n\t"
+        "v_ashrrev_i32 %2, 9, %2\n\t"
+        "v_ashrrev_i32 %3, 9, %3\n\t"
+        "v_ashrrev_i32 %4, 9, %4"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4)
+        : "v"(AV_TN(C0)), "v"(AV_TQ(C0)), "v"(AV_TN(C0 + 1)), "v"(AV_TQ(C0 + 1)), "v"(AV_TN(C0 + 2)), "v"(AV_TQ(C0 + 2)),
+          "v"(AV_TN(C0 + 3)), "v"(AV_TQ(C0 + 3)), "v"(AV_TN(C0 + 4)), "v"(AV_TQ(C0 + 4)),
+          "s"(AV_SL(C0)), "s"(AV_SL(C0 + 1)), "s"(AV_SL(C0 + 2)), "s"(AV_SL(C0 + 3)), "s"(AV_SL(C0 + 4)),
+          "v"(wtop), "v"(wbot), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4));
+#undef AV_TQ
+#undef AV_TN
+#undef AV_SL
+}
+
+template <int WIN, int OCC>
+__device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
 {
     static_assert(WIN == 15, "lane map is built for the reference's 15x15 window");
     constexpr int W_BITS = 14;
@@ -137,11 +249,11 @@ __global__ __launch_bounds__(256) void lk_track_g16_kernel(LKArgs a)
     const bool rowact = r < WIN;
     bool ok = true;
     const double FLT_SCALE_D = 1.0 / (1 << 20);
+    // byte-pair selectors of v_perm: (byte o, byte o+1) zero-extended into the two 16-bit halves; o+1 == 4 = byte 0 of the next dword
+    const uint32_t sel0 = 0x0C010C00u, sel1 = 0x0C020C01u, sel2 = 0x0C030C02u, sel3 = 0x0C040C03u;
 
     for (int level = a.g.levels - 1; level >= 0; --level) {
         const int w = a.g.w[level], h = a.g.h[level], pitch = a.g.pitch[level];
-        const uint8_t* I = PI + a.g.off[level] + AV_PYR_BORDER * pitch + AV_PYR_BORDER;
-        const uint8_t* J = PJ + a.g.off[level] + AV_PYR_BORDER * pitch + AV_PYR_BORDER;
         const int col_lo = -AV_PYR_BORDER, col_hi = pitch - AV_PYR_BORDER;
         const float scale = (float)(1. / (1 << level));
         float pvx = prevx0 * scale, pvy = prevy0 * scale;
@@ -160,44 +272,46 @@ __global__ __launch_bounds__(256) void lk_track_g16_kernel(LKArgs a)
         int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         uint32_t wtop = pack16(iw00, iw01), wbot = pack16(iw10, iw11);
 
-        // ---- stage the 18 x 24-byte neighbourhood of the I window (rows ipy-1 .., aligned dwords from cs) ---
-        const int cs = (ipx - 1) & ~3, io = (ipx - 1) - cs;
+        // ---- stage the 18 x 18-byte neighbourhood of the I window: rows ipy-1 .., bytes ipx-1 .. ipx+16 of each as five dwords
+        //      read at their (unaligned) byte address, so that every staged row starts at window column -1.  All bytes lie inside
+        //      the padded pyramid row: ipx - 1 >= -16 and ipx + 16 <= w + 15 (the 5th dword is fetched 2 bytes early and shifted).
+        // Lane map of both staging loops: lane r handles dword (r & 7) of rows 2k + (r >> 3): the global address is a
+        // wave-uniform base (padded level origin + 2k rows, scalar) plus ONE per-lane 32-bit offset, the LDS address one
+        // per-lane base plus an immediate -- no per-load index arithmetic on the vector unit.
+        const int sub = r >> 3, dwl = r & 7;
+        const uint32_t tofs = (uint32_t)(sub * (TPITCH / 4) + dwl);
         wave_lds_sync();
         {
-            uint32_t sv[7];
+            typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+            const uint8_t* L0 = PI + a.g.off[level];                    // padded origin of the level: row -16, column -16
+            const bool act = dwl < 5;                                    // 5 of the 8 slots of a row carry a dword
+            const uint32_t loff = (uint32_t)(__mul24(ipy - 1 + sub + AV_PYR_BORDER, pitch) + (ipx - 1 + AV_PYR_BORDER) + (dwl < 4 ? 4 * dwl : 14));
+            const uint32_t shamt = dwl == 4 ? 16u : 0u;
+            uint32_t sv[9];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const int idx = r + 16 * k;                 // 18 rows x 6 dwords = 108
-                const int row = idx / 6, dw = idx - row * 6;
-                const int c = cs + 4 * dw;
+            for (int k = 0; k < 9; ++k) {                               // 18 rows
                 sv[k] = 0;
-                if (idx < 108 && c >= col_lo && c + 4 <= col_hi) sv[k] = *reinterpret_cast<const uint32_t*>(I + __mul24(ipy - 1 + row, pitch) + c);
+                if (act) sv[k] = *reinterpret_cast<const u32_unaligned*>(L0 + (size_t)(2 * k) * (size_t)pitch + loff);
             }
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const int idx = r + 16 * k;
-                const int row = idx / 6, dw = idx - row * 6;
-                if (idx < 108) tile[__mul24(row, TPITCH / 4) + dw] = sv[k];
-            }
+            for (int k = 0; k < 9; ++k)
+                if (act) tile[tofs + 2 * k * (TPITCH / 4)] = sv[k] >> shamt;
         }
         wave_lds_sync();
 
-        // ---- I patch + Scharr patches of window row r: staged rows r..r+3, bytes io..io+17 of each -------------
+        // ---- this lane's row of the I patch and of the Scharr patches: staged rows r..r+2, 18 bytes of each -------------
         int iv[WIN], ixv[WIN], iyv[WIN];
         int a11 = 0, a12 = 0, a22 = 0;
         {
-            // staged byte index of window column c is c+1.  E[t][k] = (byte 2k | byte 2k+1 << 16) of staged row r+t,
-            // O[t][k] = (byte 2k+1 | byte 2k+2 << 16): window pair (c, c+1) is O[k] for c = 2k and E[k+1] for c = 2k+1.
-            uint32_t E[4][9], O12[2][8];
-            const int rr = rowact ? r : 14;                   // spare lane 15 recomputes row 14 (dropped at the reductions)
+            // staged byte index of window column c is c+1.  E[t][k] = (byte 2k | byte 2k+1 << 16) of staged row r+t; the window
+            // pair (c, c+1) of the centre row is O1[k] = (byte 2k+1 | byte 2k+2 << 16) for c = 2k and E[1][k+1] for c = 2k+1.
+            uint32_t E[3][9];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint32_t* rowp = tile + __mul24(rr + t, TPITCH / 4);
-                uint32_t d[6], B[5];
+            for (int t = 0; t < 3; ++t) {
+                const uint32_t* rowp = tile + __mul24(r + t, TPITCH / 4);
+                uint32_t B[5];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) d[k] = rowp[k];
-#pragma unroll
-                for (int k = 0; k < 5; ++k) B[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], io);
+                for (int k = 0; k < 5; ++k) B[k] = rowp[k];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {                // bytes 2k, 2k+1
                     const int b0 = 2 * k;
@@ -206,64 +320,61 @@ __global__ __launch_bounds__(256) void lk_track_g16_kernel(LKArgs a)
             }
             // (hi half of x | lo half of y << 16): the pair one column to the right of x, given y = the next pair
             auto mid = [](uint32_t x, uint32_t y) -> uint32_t { return __builtin_amdgcn_perm(y, x, 0x05040302u); };
+            // pixel pairs (c, c+1) of the centre row, c = 0..14
+            uint32_t px[WIN];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int k = 0; k < 8; ++k) px[2 * k] = mid(E[1][k], E[1][k + 1]);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) O12[t][k] = mid(E[1 + t][k], E[1 + t][k + 1]);
+            for (int k = 0; k < 7; ++k) px[2 * k + 1] = E[1][k + 1];
             // Scharr on the even window columns (pairs c = 2k, 2k+1); the odd-aligned pairs are byte permutes of those:
             //   gx[c] = t0[s+1] - t0[s-1],  gy[c] = (t1[s+1] + t1[s-1]) * 3 + t1[s] * 10,  s = c+1,
             //   t0 = (row above + row below) * 3 + row * 10,  t1 = row below - row above
-            uint32_t gxp[2][WIN + 1], gyp[2][WIN + 1];
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
+            uint32_t gxp[WIN + 1], gyp[WIN + 1];
+            {
                 uint32_t t0E[9], t1E[9];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
-                    t0E[k] = pk_add(pk_mul(pk_add(E[dy][k], E[dy + 2][k]), 3), pk_mul(E[dy + 1][k], 10));
-                    t1E[k] = pk_sub(E[dy + 2][k], E[dy][k]);
+                    t0E[k] = pk_add(pk_mul(pk_add(E[0][k], E[2][k]), 3), pk_mul(E[1][k], 10));
+                    t1E[k] = pk_sub(E[2][k], E[0][k]);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {                 // window columns (2k, 2k+1): centres O[k], left E[k], right E[k+1]
-                    gxp[dy][2 * k] = pk_sub(t0E[k + 1], t0E[k]);
-                    gyp[dy][2 * k] = pk_add(pk_mul(pk_add(t1E[k + 1], t1E[k]), 3), pk_mul(mid(t1E[k], t1E[k + 1]), 10));
+                    gxp[2 * k] = pk_sub(t0E[k + 1], t0E[k]);
+                    gyp[2 * k] = pk_add(pk_mul(pk_add(t1E[k + 1], t1E[k]), 3), pk_mul(mid(t1E[k], t1E[k + 1]), 10));
                 }
             }
             // the derivative image is zero outside the image: only windows at the border pay for the masks
             const bool inside = ipx >= 0 && ipx + WIN < w && ipy >= 0 && ipy + WIN < h;
             if (__builtin_amdgcn_ballot_w64(!inside) != 0) {
-                __builtin_amdgcn_s_sleep(0);        // a side effect keeps the compiler from if-converting this (rare) block into selects on the common path
+                // the masks are built from an opaque copy of ipx made INSIDE the block: without it the compiler hoists the 60-odd
+                // compares / selects of the mask values onto the common path and keeps only the 16 ANDs in here
+                int ipx_o = ipx;
+                asm volatile("" : "+v"(ipx_o));
+                const bool rowin = (unsigned)(ipy + r) < (unsigned)h;
 #pragma unroll
-                for (int dy = 0; dy < 2; ++dy) {
-                    const bool rowin = (unsigned)(ipy + rr + dy) < (unsigned)h;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const uint32_t m0 = (rowin && (unsigned)(ipx + 2 * k) < (unsigned)w) ? 0xFFFFu : 0u;
-                        const uint32_t m1 = (rowin && (unsigned)(ipx + 2 * k + 1) < (unsigned)w) ? 0xFFFF0000u : 0u;
-                        gxp[dy][2 * k] &= (m0 | m1); gyp[dy][2 * k] &= (m0 | m1);
-                    }
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t m0 = (rowin && (unsigned)(ipx_o + 2 * k) < (unsigned)w) ? 0xFFFFu : 0u;
+                    const uint32_t m1 = (rowin && (unsigned)(ipx_o + 2 * k + 1) < (unsigned)w) ? 0xFFFF0000u : 0u;
+                    gxp[2 * k] &= (m0 | m1); gyp[2 * k] &= (m0 | m1);
                 }
             }
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    gxp[dy][2 * k + 1] = mid(gxp[dy][2 * k], gxp[dy][2 * k + 2]);
-                    gyp[dy][2 * k + 1] = mid(gyp[dy][2 * k], gyp[dy][2 * k + 2]);
-                }
+            for (int k = 0; k < 7; ++k) {
+                gxp[2 * k + 1] = mid(gxp[2 * k], gxp[2 * k + 2]);
+                gyp[2 * k + 1] = mid(gyp[2 * k], gyp[2 * k + 2]);
+            }
             const int rnd_i = 1 << (W_BITS - 6), rnd_d = 1 << (W_BITS - 1);      // rounding terms, one register each
 #pragma unroll
+            for (int c = 0; c < WIN; c += 5) {
+                bilin5_seed(px[c], px[c + 1], px[c + 2], px[c + 3], px[c + 4], wtop, wbot, rnd_i, iv[c], iv[c + 1], iv[c + 2], iv[c + 3], iv[c + 4]);
+                bilin5<W_BITS>(gxp[c], gxp[c + 1], gxp[c + 2], gxp[c + 3], gxp[c + 4], wtop, wbot, rnd_d, ixv[c], ixv[c + 1], ixv[c + 2], ixv[c + 3], ixv[c + 4]);
+                bilin5<W_BITS>(gyp[c], gyp[c + 1], gyp[c + 2], gyp[c + 3], gyp[c + 4], wtop, wbot, rnd_d, iyv[c], iyv[c + 1], iyv[c + 2], iyv[c + 3], iyv[c + 4]);
+            }
+#pragma unroll
             for (int c = 0; c < WIN; ++c) {
-                const int k = c >> 1;
-                const uint32_t ptop = (c & 1) == 0 ? O12[0][k] : E[1][k + 1];
-                const uint32_t pbot = (c & 1) == 0 ? O12[1][k] : E[2][k + 1];
-                const int ival = dot2(ptop, wtop, dot2_keep(pbot, wbot, rnd_i)) >> (W_BITS - 5);
-                ixv[c] = dot2(gxp[0][c], wtop, dot2_keep(gxp[1][c], wbot, rnd_d)) >> W_BITS;
-                iyv[c] = dot2(gyp[0][c], wtop, dot2_keep(gyp[1][c], wbot, rnd_d)) >> W_BITS;
-                // accumulator seed of the iteration's interpolation: ((dot + R) >> 9) - ival == (dot + R - (ival << 9)) >> 9
-                iv[c] = (1 << (W_BITS - 6)) - (ival << (W_BITS - 5));
-                a11 += __mul24(ixv[c], ixv[c]);
-                a12 += __mul24(ixv[c], iyv[c]);
-                a22 += __mul24(iyv[c], iyv[c]);
+                a11 = mad24(ixv[c], ixv[c], a11);
+                a12 = mad24(ixv[c], iyv[c], a12);
+                a22 = mad24(iyv[c], iyv[c], a22);
             }
             if (!rowact) { a11 = 0; a12 = 0; a22 = 0; }
         }
@@ -289,21 +400,18 @@ __global__ __launch_bounds__(256) void lk_track_g16_kernel(LKArgs a)
                 break;
             }
             int dx0 = inx - X0, dy0 = iny - Y0;
-            if (!staged || (unsigned)dx0 > 15u || (unsigned)dy0 > 15u) {
-                X0 = min(max((inx - 6) & ~3, col_lo), col_hi - TILE);
-                Y0 = min(max(iny - 8, -AV_PYR_BORDER), h + AV_PYR_BORDER - TILE);
+            if (!staged || (unsigned)dx0 > (unsigned)(TILE_COLS - 17) || (unsigned)dy0 > (unsigned)(TILE_ROWS - 16)) {
+                X0 = min(max((inx - 6) & ~3, col_lo), col_hi - TILE_COLS);
+                Y0 = min(max(iny - 4, -AV_PYR_BORDER), h + AV_PYR_BORDER - TILE_ROWS);
                 wave_lds_sync();
-                uint32_t sv[16];
+                const uint8_t* LJ0 = PJ + a.g.off[level];
+                const uint32_t joff = (uint32_t)(__mul24(Y0 + sub + AV_PYR_BORDER, pitch) + X0 + AV_PYR_BORDER + 4 * dwl);
+                uint32_t sv[TILE_ROWS / 2];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int idx = r + 16 * k;                // 32 rows x 8 dwords
-                    sv[k] = *reinterpret_cast<const uint32_t*>(J + __mul24(Y0 + (idx >> 3), pitch) + X0 + 4 * (idx & 7));
-                }
+                for (int k = 0; k < TILE_ROWS / 2; ++k)        // 24 rows x 8 dwords
+                    sv[k] = *reinterpret_cast<const uint32_t*>(LJ0 + (size_t)(2 * k) * (size_t)pitch + joff);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int idx = r + 16 * k;
-                    tile[__mul24(idx >> 3, TPITCH / 4) + (idx & 7)] = sv[k];
-                }
+                for (int k = 0; k < TILE_ROWS / 2; ++k) tile[tofs + 2 * k * (TPITCH / 4)] = sv[k];
                 wave_lds_sync();
                 staged = true;
                 dx0 = inx - X0; dy0 = iny - Y0;
@@ -319,24 +427,17 @@ __global__ __launch_bounds__(256) void lk_track_g16_kernel(LKArgs a)
             const int sh = dx0 & 3;
             const uint32_t* rp = tile + __mul24(dy0 + r, TPITCH / 4) + (dx0 >> 2);
             uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2], d3 = rp[3], d4 = rp[4];
-            uint32_t T[5], Bt[5];
-            T[0] = __builtin_amdgcn_alignbyte(d1, d0, sh); T[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
-            T[2] = __builtin_amdgcn_alignbyte(d3, d2, sh); T[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
-            T[4] = 0;
-            // the row below comes from the next lane of the DPP row (row_shl:1)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) Bt[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T[k], 0x101, 0xF, 0xF, false);
-            Bt[4] = 0;
+            const uint32_t T0 = __builtin_amdgcn_alignbyte(d1, d0, sh), T1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            const uint32_t T2 = __builtin_amdgcn_alignbyte(d3, d2, sh), T3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+            int df[WIN];
+            jdiff5<0>(T0, T1, T2, T3, sel0, sel1, sel2, sel3, wtop, wbot, iv[0], iv[1], iv[2], iv[3], iv[4], df[0], df[1], df[2], df[3], df[4]);
+            jdiff5<5>(T0, T1, T2, T3, sel0, sel1, sel2, sel3, wtop, wbot, iv[5], iv[6], iv[7], iv[8], iv[9], df[5], df[6], df[7], df[8], df[9]);
+            jdiff5<10>(T0, T1, T2, T3, sel0, sel1, sel2, sel3, wtop, wbot, iv[10], iv[11], iv[12], iv[13], iv[14], df[10], df[11], df[12], df[13], df[14]);
             int b1 = 0, b2 = 0;
 #pragma unroll
             for (int c = 0; c < WIN; ++c) {
-                const int q = c >> 2, o = c & 3;
-                const uint32_t sel = 0x0C000C00u | (uint32_t)o | ((uint32_t)(o + 1) << 16);     // o+1 == 4 selects byte 0 of the next dword
-                const uint32_t tp = __builtin_amdgcn_perm(T[q + 1], T[q], sel);
-                const uint32_t bp = __builtin_amdgcn_perm(Bt[q + 1], Bt[q], sel);
-                const int diff = dot2(tp, wtop, dot2_keep(bp, wbot, iv[c])) >> (W_BITS - 5);
-                b1 += __mul24(diff, ixv[c]);
-                b2 += __mul24(diff, iyv[c]);
+                b1 = mad24(df[c], ixv[c], b1);
+                b2 = mad24(df[c], iyv[c], b2);
             }
             if (!rowact) { b1 = 0; b2 = 0; }
             const float fb1 = (float)(row_sum16_exact(b1) * FLT_SCALE_D);
@@ -360,6 +461,12 @@ __global__ __launch_bounds__(256) void lk_track_g16_kernel(LKArgs a)
     }
 }
 
+// Two register budgets of the same body: 4 waves per SIMD (<= 128 VGPRs, a dozen setup values spilled to scratch) and
+// 3 waves per SIMD (no spills).  The kernel is VALU-issue bound with a third of its wave cycles waiting on an
+// instruction, so the extra wave pays; AV_LK_OCC=3 selects the other build for A/B runs.
+template <int WIN> __global__ __launch_bounds__(256, 4) void lk_track_g16_kernel(LKArgs a) { lk_track_g16_body<WIN, 4>(a); }
+template <int WIN> __global__ __launch_bounds__(256, 3) void lk_track_g16_occ3_kernel(LKArgs a) { lk_track_g16_body<WIN, 3>(a); }
+
 }  // namespace
 
 int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride, int n_set, const PyrGeom& g,
@@ -378,7 +485,9 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
     a.max_iter = p.max_iter; a.eps2 = p.eps2; a.min_eig = p.min_eig;
     if (launch_pts > cap) launch_pts = cap;
     dim3 grid((launch_pts + 15) / 16, n_set);
-    hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
+    static const int occ = [] { const char* e = getenv("AV_LK_OCC"); return e ? atoi(e) : 4; }();
+    if (occ == 3) hipLaunchKernelGGL(lk_track_g16_occ3_kernel<15>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
