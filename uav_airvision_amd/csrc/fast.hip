@@ -9,21 +9,29 @@
 // of the score over their 8 neighbours; a 3-pixel border is never a corner; detect(img, mask)
 // drops keypoints whose mask pixel is 0 AFTER detection.  Integer-exact.
 //
-// MI355X mapping: one 256-thread workgroup per 64x16 tile; the 72x24 pixel tile and the 66x18
-// score tile live in LDS (5.3 KB with the candidate list), every image byte is read from HBM once
-// (+halo), scores never go to HBM.  Three phases per tile: (1) a 4-pixel necessary test on every
-// position, survivors compacted into an LDS list with a wave ballot + one LDS atomic per wave,
-// (2) the ~200-op corner score for the compacted candidates only (dense lanes instead of a
-// divergent early-out), (3) 3x3 non-max suppression in LDS.  Survivors are appended with one atomic each (a few thousand per image), either to a
-// flat list or straight into per-grid-cell candidate lists for the feature adder.
-// Bound: HBM read of the image (w*h bytes) -- the score arithmetic is ~200 VALU ops/pixel.
+// MI355X mapping: one 256-thread workgroup per 64x48 tile; the 72x56 pixel tile and the 72x50 score tile live in
+// LDS (every image byte is read from HBM once + halo, scores never go to HBM).  Three phases per tile, all of them
+// working on DWORDS of four horizontally adjacent pixels (the kernel is LDS-latency bound, not VALU bound: byte-wide
+// LDS reads were 4x the instructions):
+//  (1) the 4-pixel necessary test: a lane reads the five dwords that hold the compass pixels of its four positions,
+//      survivors are compacted into a wave-private LDS list with ballots (no atomics, no barrier before phase 2);
+//  (2) the ~200-op corner score for the compacted candidates only (dense lanes instead of a divergent early-out);
+//  (3) 3x3 non-max suppression, again a dword of four scores per lane with its eight neighbouring dwords; quads with no
+//      positive score (most) leave after one read.
+// Survivors go to an LDS list first, then ONE returning global atomic per (tile, grid cell) reserves their slots in the
+// per-cell candidate lists of the feature adder (or in a flat list).
+// Bound: HBM read of the image (w*h bytes) -- the score arithmetic is ~200 VALU ops per candidate.
+#include <stdlib.h>
+
 #include "av_common.h"
 
 namespace {
 
 constexpr int TW = 64, TH = 48;
-constexpr int PW = TW + 8, PH = TH + 8;     // pixel tile
-constexpr int SW = TW + 2, SH = TH + 2;     // score tile
+constexpr int PW = TW + 8, PH = TH + 8;     // pixel tile: columns x0-4 .. x0+67 (pc = x - x0 + 4), rows y0-4 .. y0+51
+constexpr int PWD = PW / 4;                 // 18 dwords per pixel row
+constexpr int SP = PW, SH = TH + 2;         // score tile: column index = pc (same dword phase as the pixels), row sr = y - y0 + 1
+constexpr int SPD = SP / 4;
 constexpr int MAXLC = 16;                   // grid cells one tile may overlap
 
 struct FastArgs {
@@ -37,6 +45,7 @@ struct FastArgs {
     uint32_t* kp; int* count; int cap;
     uint32_t* cell_kp; int* cell_count; int cell_cap, gh, gw, grid_col, n_cells;
     int* n_fast; int* overflow; int stat_stride;
+    int dbg;
 };
 
 __device__ __forceinline__ int fast_score(const uint8_t* c, int t)
@@ -68,26 +77,41 @@ __device__ __forceinline__ int fast_score(const uint8_t* c, int t)
 
 __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t pix[PH * PW];
-    __shared__ uint8_t sc[SH * SW];
-    // candidate lists, one private segment per wavefront (a wavefront visits every fourth chunk of 64 positions)
-    constexpr int SEG = ((SH * SW + 255) / 256) * 64;
+    __shared__ __attribute__((aligned(16))) uint8_t pix[PH * PW + 16];     // +16: the last quad of the last row reads one dword past it
+    __shared__ __attribute__((aligned(16))) uint8_t sc[SH * SP];
+    // candidate lists, one private segment per wavefront (a wavefront visits every fourth chunk of 64 quads, 4 positions each)
+    constexpr int NQ = SH * PWD;                                  // 900 quad positions
+    constexpr int SEG = ((NQ + 255) / 256) * 64 * 4;
     __shared__ uint16_t cand[4 * SEG];
     const int img_i = blockIdx.z;
     const uint8_t* img = a.img + img_i * a.img_stride;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int tid = threadIdx.x;
 
-    // pixel tile: 24 rows x 72 bytes from (x0-4, y0-4).  Tiles whose footprint lies inside the (padded) image copy dwords
-    // (x0 is a multiple of 64, so x0-4 is dword aligned when pitch and base are); the others clamp per byte.  Pixels
-    // outside the image never reach a valid output (corners need x, y in [3, dim-3)), so clamp vs reflect is immaterial.
-    const bool inside = x0 - 4 >= -a.border && x0 - 4 + PW <= a.w + a.border && y0 - 4 >= -a.border && y0 - 4 + PH <= a.h + a.border &&
+    // pixel tile: 56 rows x 72 bytes from (x0-4, y0-4).  Tiles whose rows lie inside the (padded) image copy dwords
+    // (x0 is a multiple of 64, so x0-4 is dword aligned when pitch and base are); dwords beyond the padded row are zero;
+    // the other tiles clamp per byte.  Pixels outside the image never reach a valid output (corners need x, y in
+    // [3, dim-3)), so clamp vs reflect vs zero is immaterial.
+    const bool inside = x0 - 4 >= -a.border && y0 - 4 >= -a.border && y0 - 4 + PH <= a.h + a.border &&
                         ((a.img_pitch | (int)(a.img_stride & 3) | (int)(reinterpret_cast<uintptr_t>(a.img) & 3)) & 3) == 0;
+    uint32_t* pixw = reinterpret_cast<uint32_t*>(pix);
+    // The mask bytes of the four pixels each lane will judge in phase 3 are fetched NOW, with the pixel tile: a mask read
+    // behind the non-max suppression was a dependent HBM round trip in the middle of every tile.
+    constexpr int NIT3 = (TW / 4) * TH / 256;
+    uint32_t mask4[NIT3];
+    const bool mask_dw = a.mask && (((a.w | (int)(a.mask_stride & 3) | (int)(reinterpret_cast<uintptr_t>(a.mask) & 3)) & 3) == 0);
+#pragma unroll
+    for (int it = 0; it < NIT3; ++it) {
+        const int i = tid + 256 * it;
+        const int r = i / (TW / 4), x = x0 + 4 * (i - r * (TW / 4)), y = y0 + r;
+        mask4[it] = 0xFFFFFFFFu;
+        if (mask_dw) mask4[it] = (x + 4 <= a.w && y < a.h) ? *reinterpret_cast<const uint32_t*>(a.mask + img_i * a.mask_stride + (size_t)y * a.w + x) : 0u;
+    }
     if (inside) {
-        uint32_t* pixw = reinterpret_cast<uint32_t*>(pix);
-        for (int i = tid; i < PH * (PW / 4); i += 256) {
-            const int r = i / (PW / 4), c = i - r * (PW / 4);
-            pixw[i] = *reinterpret_cast<const uint32_t*>(img + (ptrdiff_t)(y0 - 4 + r) * a.img_pitch + (x0 - 4) + 4 * c);
+        for (int i = tid; i < PH * PWD; i += 256) {
+            const int r = i / PWD, c = i - r * PWD;
+            const int xb = x0 - 4 + 4 * c;
+            pixw[i] = xb + 4 <= a.w + a.border ? *reinterpret_cast<const uint32_t*>(img + (ptrdiff_t)(y0 - 4 + r) * a.img_pitch + xb) : 0u;
         }
     } else {
         for (int i = tid; i < PH * PW; i += 256) {
@@ -96,41 +120,56 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
             pix[i] = img[(size_t)y * a.img_pitch + x];
         }
     }
+    if (tid < 4) pixw[PH * PWD + tid] = 0;
     __syncthreads();
-    // Phase 1: cheap necessary condition on the 4 compass pixels of the ring (any 9-arc contains at
-    // least two of them), survivors compacted into an LDS list so that phase 2 runs dense.
+    // Phase 1: cheap necessary condition on the 4 compass pixels of the ring (any 9-arc contains at least two of them) for the
+    // four positions pc = 4q .. 4q+3 of score row sr (pixel row sr+3): dwords U (3 rows up), D (3 rows down), L, C, R of the row.
+    uint32_t* scw = reinterpret_cast<uint32_t*>(sc);
     const int lane = tid & 63, wave = tid >> 6;
     int wcnt = 0;                                   // candidates found by this wavefront so far (wavefront-uniform)
-    for (int i0 = 0; i0 < SH * SW; i0 += 256) {
+    const int t = a.threshold;
+    for (int i0 = 0; i0 < NQ; i0 += 256) {
         const int i = i0 + tid;
-        bool cand_flag = false;
-        if (i < SH * SW) {
-            const int r = i / SW, c = i - r * SW;
-            const int y = y0 - 1 + r, x = x0 - 1 + c;
-            sc[i] = 0;
-            if (x >= 3 && x < a.w - 3 && y >= 3 && y < a.h - 3) {
-                const uint8_t* p = &pix[(r + 3) * PW + (c + 3)];
-                const int v = p[0], t = a.threshold;
-                const int d0 = v - (int)p[3 * PW], d4 = v - (int)p[3], d8 = v - (int)p[-3 * PW], d12 = v - (int)p[-3];
-                const int nb = (d0 > t) + (d4 > t) + (d8 > t) + (d12 > t);
-                const int nd = (d0 < -t) + (d4 < -t) + (d8 < -t) + (d12 < -t);
-                cand_flag = nb >= 2 || nd >= 2;
+        bool cf[4] = {false, false, false, false};
+        int sr = 0, q = 0;
+        if (i < NQ) {
+            sr = i / PWD; q = i - sr * PWD;
+            scw[i] = 0;
+            const int y = y0 - 1 + sr;
+            if (y >= 3 && y < a.h - 3 && !(a.dbg & 2)) {
+                const uint32_t* rowc = pixw + (sr + 3) * PWD + q;
+                const uint32_t C = rowc[0], L = q > 0 ? rowc[-1] : 0u, R = rowc[1];
+                const uint32_t U = rowc[-3 * PWD], D = rowc[3 * PWD];
+                const uint32_t R3 = __builtin_amdgcn_alignbyte(R, C, 3), L3 = __builtin_amdgcn_alignbyte(C, L, 1);      // p[+3], p[-3] of the four positions
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int pc = 4 * q + k, x = x0 - 4 + pc;
+                    const int v = (int)((C >> (8 * k)) & 0xFF);
+                    const int d0 = v - (int)((D >> (8 * k)) & 0xFF), d4 = v - (int)((R3 >> (8 * k)) & 0xFF);
+                    const int d8 = v - (int)((U >> (8 * k)) & 0xFF), d12 = v - (int)((L3 >> (8 * k)) & 0xFF);
+                    const int nb = (d0 > t) + (d4 > t) + (d8 > t) + (d12 > t);
+                    const int nd = (d0 < -t) + (d4 < -t) + (d8 < -t) + (d12 < -t);
+                    cf[k] = (nb >= 2 || nd >= 2) && pc >= 3 && pc <= TW + 4 && x >= 3 && x < a.w - 3;
+                }
             }
         }
         // ordered compaction into this wavefront's own segment: no LDS atomic, no cross-lane broadcast
-        const unsigned long long b = __ballot(cand_flag);
-        if (cand_flag) cand[wave * SEG + wcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0))] = (uint16_t)i;
-        wcnt += __popcll(b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long b = __ballot(cf[k]);
+            if (cf[k]) cand[wave * SEG + wcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0))] = (uint16_t)(sr * SP + 4 * q + k);
+            wcnt += __popcll(b);
+        }
     }
     // Phase 2: full corner score only for the candidates -- each wavefront scores its own list (the LDS traffic of one
     // wavefront is ordered, so no workgroup barrier is needed between the two phases)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int k = lane; k < wcnt; k += 64) {
+    if (!(a.dbg & 1)) for (int k = lane; k < wcnt; k += 64) {
         const int i = cand[wave * SEG + k];
-        const int r = i / SW, c = i - r * SW;
-        sc[i] = (uint8_t)fast_score(&pix[(r + 3) * PW + (c + 3)], a.threshold);
+        const int sr = i / SP, pc = i - sr * SP;
+        sc[i] = (uint8_t)fast_score(&pix[(sr + 3) * PW + pc], t);
     }
     __syncthreads();
     // Phase 3: 3x3 non-max suppression + mask; survivors go to an LDS list first so that the tile issues
@@ -138,36 +177,55 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
     // instead of one per keypoint.
     __shared__ uint32_t surv_word[TW * TH / 4];             // strict 3x3 maxima: at most one per 2x2 block
     __shared__ int surv_cell[TW * TH / 4];
-    __shared__ int nsurv, cell_base[MAXLC], flat_base;
+    __shared__ int nsurv, cell_base[MAXLC], cell_cnt[MAXLC], flat_base;
     if (tid == 0) nsurv = 0;
+    if (tid < MAXLC) cell_cnt[tid] = 0;
     __syncthreads();
     // grid cells overlapped by this tile: columns cx0..cx0+ncx-1, rows cy0..cy0+ncy-1 (ncx*ncy <= MAXLC)
     const int cx0 = a.cell_kp ? x0 / a.gw : 0, cy0 = a.cell_kp ? y0 / a.gh : 0;
     const int ncx = a.cell_kp ? (min(x0 + TW - 1, a.w - 1) / a.gw - cx0 + 1) : 1;
     const int ncy = a.cell_kp ? (min(y0 + TH - 1, a.h - 1) / a.gh - cy0 + 1) : 1;
+    // quads of the tile interior: columns pc = 4q .. 4q+3, q = 1..16 (x = x0 .. x0+63), score rows sr = 1..48 (y = y0 .. y0+47)
 #pragma unroll
-    for (int k = 0; k < (TW * TH) / 256; ++k) {
-        int i = tid + 256 * k;
-        int r = i / TW, c = i - r * TW;
-        int x = x0 + c, y = y0 + r;
-        const uint8_t* p = &sc[(r + 1) * SW + (c + 1)];
-        int s = p[0];
-        bool keep = s > 0 && x < a.w && y < a.h &&
-                    s > p[-1] && s > p[1] && s > p[-SW - 1] && s > p[-SW] && s > p[-SW + 1] &&
-                    s > p[SW - 1] && s > p[SW] && s > p[SW + 1];
-        if (keep && a.mask) keep = a.mask[img_i * a.mask_stride + (size_t)y * a.w + x] != 0;
-        if (keep) {
-            const int slot = atomicAdd(&nsurv, 1);            // LDS atomic; a tile has <= TW*TH/4 strict maxima
-            surv_word[slot] = ((uint32_t)s << AV_KP_RASTER_BITS) | (AV_KP_RASTER_MASK - (uint32_t)(y * a.w + x));
-            surv_cell[slot] = a.cell_kp ? ((y / a.gh - cy0) * ncx + (x / a.gw - cx0)) : 0;      // tile-local cell index
+    for (int it = 0; it < (TW / 4) * TH / 256; ++it) {
+        const int i = tid + 256 * it;
+        const int r = i / (TW / 4), q = 1 + (i - r * (TW / 4));
+        const uint32_t* rowc = scw + (r + 1) * SPD + q;
+        const uint32_t B = rowc[0];
+        if (B == 0 || (a.dbg & 4)) continue;                                 // no positive score among the four pixels
+        // per score row the 6-byte window [pc-1 .. pc+4] as (lo, hi): pixel k sees bytes k, k+1, k+2
+        uint32_t lo[3], hi[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const uint32_t* rp = rowc + (d - 1) * SPD;
+            const uint32_t A = rp[-1], Bm = rp[0], Cn = rp[1];
+            lo[d] = __builtin_amdgcn_alignbyte(Bm, A, 3); hi[d] = __builtin_amdgcn_alignbyte(Cn, Bm, 3);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int s = (int)((B >> (8 * k)) & 0xFF);
+            if (s == 0) continue;
+            const int x = x0 + 4 * (q - 1) + k, y = y0 + r;
+            bool keep = x < a.w && y < a.h;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const uint32_t tri = (uint32_t)((((unsigned long long)hi[d] << 32) | lo[d]) >> (8 * k));       // bytes: left, centre, right
+                keep = keep && s > (int)(tri & 0xFF) && s > (int)((tri >> 16) & 0xFF) && (d == 1 || s > (int)((tri >> 8) & 0xFF));
+            }
+            if (keep && a.mask) keep = mask_dw ? ((mask4[it] >> (8 * k)) & 0xFF) != 0 : a.mask[img_i * a.mask_stride + (size_t)y * a.w + x] != 0;
+            if (keep) {
+                const int slot = atomicAdd(&nsurv, 1);            // LDS atomic; a tile has <= TW*TH/4 strict maxima
+                const int lc = a.cell_kp ? ((y / a.gh - cy0) * ncx + (x / a.gw - cx0)) : 0;      // tile-local cell index
+                surv_word[slot] = ((uint32_t)s << AV_KP_RASTER_BITS) | (AV_KP_RASTER_MASK - (uint32_t)(y * a.w + x));
+                surv_cell[slot] = lc | (atomicAdd(&cell_cnt[lc], 1) << 8);          // rank inside its cell (lists are unordered: any rank will do)
+            }
         }
     }
     __syncthreads();
     const int ns = nsurv;
     if (ns == 0) return;
     if (tid < ncx * ncy) {
-        int cnt = 0;
-        for (int q = 0; q < ns; ++q) cnt += surv_cell[q] == tid;
+        const int cnt = cell_cnt[tid];
         int base = 0;
         if (a.cell_kp && cnt > 0) {
             const int cell = (cy0 + tid / ncx) * a.grid_col + (cx0 + tid % ncx);
@@ -188,9 +246,7 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
             else if (a.overflow) atomicOr(&a.overflow[img_i * a.stat_stride], 1);
         }
         if (a.cell_kp) {
-            const int lc = surv_cell[q];
-            int rank = 0;
-            for (int e = 0; e < q; ++e) rank += surv_cell[e] == lc;
+            const int lc = surv_cell[q] & 0xFF, rank = surv_cell[q] >> 8;
             const int cell = (cy0 + lc / ncx) * a.grid_col + (cx0 + lc % ncx);
             const int idx = cell_base[lc] + rank;
             if (idx < a.cell_cap) a.cell_kp[((size_t)img_i * a.n_cells + cell) * a.cell_cap + idx] = word;
@@ -222,6 +278,7 @@ int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, int bo
     a.kp = kp; a.count = count; a.cap = cap;
     a.cell_kp = cell_kp; a.cell_count = cell_count; a.cell_cap = cell_cap; a.gh = gh; a.gw = gw;
     a.grid_col = grid_col; a.n_cells = n_cells; a.n_fast = n_fast; a.overflow = overflow; a.stat_stride = stat_stride;
+    { const char* e = getenv("AV_FAST_DBG"); a.dbg = e ? atoi(e) : 0; }
     dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, n_img);
     hipLaunchKernelGGL(fast_kernel, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();

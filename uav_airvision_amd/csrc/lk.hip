@@ -461,11 +461,12 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
     }
 }
 
-// Two register budgets of the same body: 4 waves per SIMD (<= 128 VGPRs, a dozen setup values spilled to scratch) and
-// 3 waves per SIMD (no spills).  The kernel is VALU-issue bound with a third of its wave cycles waiting on an
-// instruction, so the extra wave pays; AV_LK_OCC=3 selects the other build for A/B runs.
+// Register budgets of the same body: 111 VGPRs fit 4 waves per SIMD without spills; 5 and 6 waves per SIMD spill 9 / 23
+// setup values to scratch.  The kernel is VALU-issue bound with part of its wave cycles waiting on an instruction, so the
+// extra waves can pay; AV_LK_OCC selects the build for A/B runs (default: the fastest measured).
 template <int WIN> __global__ __launch_bounds__(256, 4) void lk_track_g16_kernel(LKArgs a) { lk_track_g16_body<WIN, 4>(a); }
-template <int WIN> __global__ __launch_bounds__(256, 3) void lk_track_g16_occ3_kernel(LKArgs a) { lk_track_g16_body<WIN, 3>(a); }
+template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_occ5_kernel(LKArgs a) { lk_track_g16_body<WIN, 5>(a); }
+template <int WIN> __global__ __launch_bounds__(256, 6) void lk_track_g16_occ6_kernel(LKArgs a) { lk_track_g16_body<WIN, 6>(a); }
 
 }  // namespace
 
@@ -486,7 +487,8 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
     if (launch_pts > cap) launch_pts = cap;
     dim3 grid((launch_pts + 15) / 16, n_set);
     static const int occ = [] { const char* e = getenv("AV_LK_OCC"); return e ? atoi(e) : 4; }();
-    if (occ == 3) hipLaunchKernelGGL(lk_track_g16_occ3_kernel<15>, grid, dim3(256), 0, st, a);
+    if (occ == 5) hipLaunchKernelGGL(lk_track_g16_occ5_kernel<15>, grid, dim3(256), 0, st, a);
+    else if (occ == 6) hipLaunchKernelGGL(lk_track_g16_occ6_kernel<15>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;
