@@ -311,17 +311,17 @@ def main():
                     idx.append(s); ts.append(m.timestamp); gy.append(m.angular_velocity); ac.append(m.linear_acceleration)
         imu_steps.append((np.array(idx, np.int32), np.array(ts, np.float64), np.array(gy, np.float64).reshape(-1, 3),
                           np.array(ac, np.float64).reshape(-1, 3)))
-    # The filter's copy of the IMU feed.  Staggered start: the filters of the odd replicas receive their first IMU samples one
-    # step late, so they are not yet initialised at step 0 (that frame's features are dropped, msckf.py:182-183) and start at
-    # step 1 -- from then on half of the filters run the two-camera prune on even steps and half on odd ones, the steady
-    # state of unsynchronised streams, instead of all 1024 in lock-step.  The front-end sees every sample on time.
+    # The filter's copy of the IMU feed.  Staggered start: the filters of the odd replicas never see their first 10 IMU samples
+    # (one frame period), so the sample that completes their gravity initialisation (the 200th, msckf.py:172-175) is newer than
+    # frame 0: by the data-defined rule of the library they are not live at step 0 (that frame's features are dropped,
+    # msckf.py:182-183) and start at step 1, whatever the thread timing.  From then on half of the filters run the two-camera
+    # prune on even steps and half on odd ones -- the steady state of unsynchronised streams -- instead of all 1024 in
+    # lock-step.  The front-end sees every sample.
     imu_steps_f = list(imu_steps)
-    if stagger and F > 1:
-        late = ((imu_steps[0][0] // U) % 2) == 1
+    if stagger:
         i0, t0_, g0, a0 = imu_steps[0]
-        i1, t1_, g1, a1 = imu_steps[1]
-        imu_steps_f[0] = (i0[~late], t0_[~late], g0[~late], a0[~late])
-        imu_steps_f[1] = (np.concatenate([i0[late], i1]), np.concatenate([t0_[late], t1_]), np.concatenate([g0[late], g1]), np.concatenate([a0[late], a1]))
+        drop = (((i0 // U) % 2) == 1) & (t0_ < t0_.min() + 10.0 / 200.0 - 1e-6)
+        imu_steps_f[0] = (i0[~drop], t0_[~drop], g0[~drop], a0[~drop])
     frame_ts = [[streams[s % U].frame_time(k) for s in range(S)] for k in range(F)]
     gen_s = time.time() - t_gen
 

@@ -879,9 +879,17 @@ struct UpdArgs {
     double* dx;                                  // [n]
     double obs_noise;
     int m;                                       // total stacked rows
+    double* Sbuf;                                // batched back end: S = H P H^T + s^2 I, [k][ld] (lower triangle used)
 };
 
 constexpr int UT = 1024;
+
+// When is the stacked Jacobian QR-compressed to its nc non-zero columns?  The reference compresses when m > n
+// (msckf.py:554); any thin QR leaves delta_x and P+ unchanged, so the choice is free.  A Householder QR costs nc
+// dependent reflector steps, the back end scales with k = rows kept: compressing 130 rows to 114 costs more than it
+// saves, compressing 1480 rows to 12 is the whole point.  k never exceeds 144 (S and T^T live in [ld][ld] buffers).
+__host__ __device__ inline bool upd_compress(int m, int nc) { return m > nc && (2 * m > 3 * nc || m > 144); }
+__host__ __device__ inline int upd_k(int m, int nc) { return upd_compress(m, nc) ? nc : m; }
 
 __device__ __forceinline__ double block_sum(double v, double* red)
 {
@@ -1163,7 +1171,8 @@ __device__ __forceinline__ void update_front(const UpdArgs& a)
         }
         __syncthreads();
     }
-    const bool qr_regs = m > nc && ((nc + 1 <= 128 && m <= 256) || (nc + 1 <= 64 && m <= 512) || (nc + 1 <= 32 && m <= 1024) || (nc + 1 <= 16 && m <= 2048));
+    const bool comp = upd_compress(m, nc);
+    const bool qr_regs = comp && ((nc + 1 <= 128 && m <= 256) || (nc + 1 <= 64 && m <= 512) || (nc + 1 <= 32 && m <= 1024) || (nc + 1 <= 16 && m <= 2048));
     if (!qr_regs) {
         // gather the gated feature blocks into Wt (coalesced writes along a column)
         for (int i = tid; i < m * nc; i += UT) {
@@ -1182,7 +1191,7 @@ __device__ __forceinline__ void update_front(const UpdArgs& a)
         else if (nc + 1 <= 32 && m <= 1024) qr_in_registers<2, 16>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
         else if (nc + 1 <= 16 && m <= 1536) qr_in_registers<1, 24>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
         else qr_in_registers<1, 32>(a, m, nc, srcrow, vb0, vb0 + m, qsc, Wt, ldt, rcol);
-    } else if (m > nc) {
+    } else if (comp) {
         const int wave = tid >> 6, lane = tid & 63, nw = UT / 64;
         // Two LDS buffers hold the current and the next reflector column.  The wavefront that updates column j+1
         // in step j also accumulates its squared norm and stages it as the next reflector, so a Householder step
@@ -1328,7 +1337,7 @@ __device__ __forceinline__ void update_back(const UpdArgs& a)
     const size_t ldt = a.ldt;
     double* Wt = a.W;
     double* rcol = Wt + (size_t)nc * ldt;
-    const int k = m > nc ? nc : m;
+    const int k = upd_k(m, nc);
     // 3. T = H_thin P (k x n): T[r][c] = sum_q Wt[q][r] P[cols[q]][c];  4. S = T H_thin^T + s^2 I (packed lower triangle in
     //    LDS): S[r][c] = sum_q T[r][cols[q]] Wt[q][c].  Both through panel_gemm (LDS-staged operands, 4x4 register tiles).
     double* pa = Lp + (size_t)k * (k + 1) / 2 + 8;
@@ -1469,6 +1478,218 @@ __device__ __forceinline__ void update_back(const UpdArgs& a)
     __syncthreads();
     stamp(6);
 }
+// ================================================================================================
+// Back end of the stacked update for MANY streams (av_msckf_batch_*): the three GEMM-shaped phases as wide-grid tile
+// kernels over all streams (64 x 64 output tile per 256-thread workgroup, 4 x 4 per thread, operands staged through LDS in
+// panels of 16), and the two dependent chains -- Cholesky of S and the forward substitution -- in a 256-thread kernel per
+// stream that holds only the packed factor in LDS.  The single-workgroup update_back above does the same arithmetic inside
+// one 1024-thread workgroup at 128 VGPRs: it owns a whole CU for ~0.4 ms per stream while using a few percent of it, and
+// nothing else can be resident beside it; these kernels are <= 64 VGPRs each, so the front-end's kernels share the CUs.
+//   T^T = P[:, cols] H_thin^T   (n x k)      upd_tt_kernel
+//   S   = H_thin P_cc H_thin^T + s^2 I        upd_s_kernel      (rows cols[q] of T^T are exactly P_cc H_thin^T)
+//   L L^T = S;  Y = L^-1 [T | r];  dx = Y^T y_r      upd_solve_kernel
+//   P  <- sym(P - Y^T Y)  in place                     upd_p_kernel
+// fp64 MFMA is not used: on MI355X the fp64 matrix peak equals the fp64 vector peak (78.6 TFLOP/s, CDNA4 halved the
+// MI300's fp64 matrix rate), so v_mfma_f64_16x16x4 buys no throughput over v_fma_f64 and costs the fragment shuffles.
+// ================================================================================================
+constexpr int GT = 64, GQ = 16, GP = GT + 4;      // tile edge, panel depth, LDS pitch in doubles (16-B aligned rows)
+
+template <typename FA, typename FB>
+__device__ __forceinline__ void gemm_tile64(int Q, int r0, int c0, FA loadA, FB loadB, double (&acc)[4][4])
+{
+    __shared__ __attribute__((aligned(16))) double pa[GQ * GP], pb[GQ * GP];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int q0 = 0; q0 < Q; q0 += GQ) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 256 * u, q = idx >> 6, e = idx & 63;
+            const bool in = q0 + q < Q;
+            pa[q * GP + e] = in ? loadA(q0 + q, r0 + e) : 0.0;
+            pb[q * GP + e] = in ? loadB(q0 + q, c0 + e) : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) {
+            const av_d4 av = *reinterpret_cast<const av_d4*>(&pa[q * GP + 4 * ty]);
+            const av_d4 bv = *reinterpret_cast<const av_d4*>(&pb[q * GP + 4 * tx]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(av[i], bv[j], acc[i][j]);
+        }
+    }
+}
+
+// T^T[c][r] = sum_q P[cols[q]][c] * Wt[q][r]   (c < n, r < k), stored [n][ld] in a.T
+__global__ __launch_bounds__(256) void upd_tt_kernel(const UpdArgs* __restrict__ arr, int tiles_k)
+{
+    const UpdArgs a = arr[blockIdx.y];
+    if (a.m <= 0) return;
+    const int k = upd_k(a.m, a.nc), n = a.n;
+    const int r0 = (blockIdx.x / tiles_k) * GT, c0 = (blockIdx.x % tiles_k) * GT;      // rows: state index, columns: stacked row
+    if (r0 >= n || c0 >= k) return;
+    const size_t ldt = a.ldt;
+    double acc[4][4];
+    gemm_tile64(a.nc, r0, c0,
+                [&](int q, int c) { return c < n ? a.P[(size_t)a.cols[q] * a.ld + c] : 0.0; },
+                [&](int q, int r) { return r < k ? a.W[(size_t)q * ldt + r] : 0.0; }, acc);
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = r0 + 4 * ty + i;
+        // columns at or beyond k (rounded up to the 4-wide store) belong to nobody: a 64-wide tile may reach past the row pitch
+        if (c < n && c0 + 4 * tx < k) { av_d4 o = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]}; *reinterpret_cast<av_d4*>(a.T + (size_t)c * a.ld + c0 + 4 * tx) = o; }
+    }
+}
+
+// S[r][c] = sum_q T^T[cols[q]][r] * Wt[q][c] + s^2 [r == c]   (r, c < k; tiles on and below the diagonal)
+__global__ __launch_bounds__(256) void upd_s_kernel(const UpdArgs* __restrict__ arr)
+{
+    const UpdArgs a = arr[blockIdx.y];
+    if (a.m <= 0) return;
+    const int k = upd_k(a.m, a.nc);
+    int tr = (int)((sqrtf(8.f * blockIdx.x + 1.f) - 1.f) * 0.5f);              // triangular tile index -> (tr, tc), tc <= tr
+    while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
+    while (tr * (tr + 1) / 2 > (int)blockIdx.x) --tr;
+    const int tc = blockIdx.x - tr * (tr + 1) / 2;
+    const int r0 = tr * GT, c0 = tc * GT;
+    if (r0 >= k) return;
+    const size_t ldt = a.ldt;
+    double acc[4][4];
+    gemm_tile64(a.nc, r0, c0,
+                [&](int q, int r) { return r < k ? a.T[(size_t)a.cols[q] * a.ld + r] : 0.0; },
+                [&](int q, int c) { return c < k ? a.W[(size_t)q * ldt + c] : 0.0; }, acc);
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 4 * ty + i;
+        if (r < k && c0 + 4 * tx < k) {
+            av_d4 o = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (c0 + 4 * tx + j == r) o[j] += a.obs_noise;
+            *reinterpret_cast<av_d4*>(a.Sbuf + (size_t)r * a.ld + c0 + 4 * tx) = o;       // k <= 144 < ld: the 4-wide store stays inside the row
+        }
+    }
+}
+
+// Cholesky S = L L^T (packed lower triangle in LDS), Y = L^-1 [T | r_thin] (one thread per right-hand side), dx = Y^T y_r.
+__global__ __launch_bounds__(256) void upd_solve_kernel(const UpdArgs* __restrict__ arr)
+{
+    extern __shared__ double Lp[];
+    const UpdArgs a = arr[blockIdx.x];
+    if (a.m <= 0) return;
+    const int tid = threadIdx.x, n = a.n, nc = a.nc;
+    const int k = upd_k(a.m, nc);
+    double* rcol = a.W + (size_t)nc * a.ldt;
+    for (int e = tid; e < k * k; e += 256) {
+        const int r = e / k, c = e - r * k;
+        if (c <= r) Lp[r * (r + 1) / 2 + c] = a.Sbuf[(size_t)r * a.ld + c];
+    }
+    __syncthreads();
+    // right-looking, column scaling deferred: step j subtracts a_rj a_cj / d_j from the trailing block (one barrier per column)
+    for (int j = 0; j < k; ++j) {
+        const double inv = 1.0 / Lp[j * (j + 1) / 2 + j];
+        for (int r = j + 1 + (tid >> 4); r < k; r += 16) {
+            const double lrj = Lp[r * (r + 1) / 2 + j] * inv;
+            for (int c = j + 1 + (tid & 15); c <= r; c += 16) Lp[r * (r + 1) / 2 + c] -= lrj * Lp[c * (c + 1) / 2 + j];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < k * k; e += 256) {
+        const int r = e / k, c = e - r * k;
+        if (c < r) Lp[r * (r + 1) / 2 + c] /= sqrt(Lp[c * (c + 1) / 2 + c]);
+    }
+    __syncthreads();
+    for (int j = tid; j < k; j += 256) Lp[j * (j + 1) / 2 + j] = sqrt(Lp[j * (j + 1) / 2 + j]);
+    __syncthreads();
+    // forward substitution, blocked by 8 rows: right-hand side c < n is row c of T^T (contiguous), c == n is r_thin
+    for (int c = tid; c <= n; c += 256) {
+        const double* src = c < n ? a.T + (size_t)c * a.ld : rcol;
+        double* y = c < n ? a.Kt + c : rcol;
+        const size_t st_ = c < n ? (size_t)a.ld : 1;
+        for (int i0 = 0; i0 < k; i0 += 8) {
+            double acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = i0 + u < k ? src[i0 + u] : 0.0;
+            const double* Lr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = min(i0 + u, k - 1); Lr[u] = Lp + (size_t)i * (i + 1) / 2; }
+#pragma unroll 4
+            for (int q = 0; q < i0; ++q) {
+                const double yq = y[(size_t)q * st_];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] -= Lr[u][q] * yq;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u < k) {
+#pragma unroll
+                    for (int w = 0; w < u; ++w) acc[u] -= Lr[u][i0 + w] * acc[w];
+                    acc[u] /= Lr[u][i0 + u];
+                    y[(size_t)(i0 + u) * st_] = acc[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < n; c += 256) {
+        double sacc = 0;
+#pragma unroll 8
+        for (int i = 0; i < k; ++i) sacc += a.Kt[(size_t)i * a.ld + c] * rcol[i];
+        a.dx[c] = sacc;
+    }
+}
+
+// P <- sym(P - Y^T Y) in place (msckf.py:597-602): the 4 x 4 sub-tiles on and below the diagonal are formed, each owner
+// reads its sub-tile of P and the mirror sub-tile, then writes both -- every unordered pair {(r,c), (c,r)} has one owner.
+__global__ __launch_bounds__(256) void upd_p_kernel(const UpdArgs* __restrict__ arr)
+{
+    const UpdArgs a = arr[blockIdx.y];
+    if (a.m <= 0) return;
+    const int n = a.n, k = upd_k(a.m, a.nc);
+    int tr = (int)((sqrtf(8.f * blockIdx.x + 1.f) - 1.f) * 0.5f);
+    while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
+    while (tr * (tr + 1) / 2 > (int)blockIdx.x) --tr;
+    const int tc = blockIdx.x - tr * (tr + 1) / 2;
+    const int r0 = tr * GT, c0 = tc * GT;
+    if (r0 >= n) return;
+    double t[4][4];
+    gemm_tile64(k, r0, c0,
+                [&](int q, int r) { return r < n ? a.Kt[(size_t)q * a.ld + r] : 0.0; },
+                [&](int q, int c) { return c < n ? a.Kt[(size_t)q * a.ld + c] : 0.0; }, t);
+    const int R0 = r0 + 4 * (threadIdx.x >> 4), C0 = c0 + 4 * (threadIdx.x & 15);
+    if (R0 < C0 || R0 >= n) return;
+    double pr[4][4], pm[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = R0 + i, c = C0 + j;
+            const bool in = r < n && c < n;
+            pr[i][j] = in ? a.P[(size_t)r * a.ld + c] : 0.0;
+            pm[i][j] = in ? a.P[(size_t)c * a.ld + r] : 0.0;
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = R0 + i, c = C0 + j;
+            if (r < n && c < n) {
+                // (inside a diagonal sub-tile the owner holds (r,c) and (c,r) itself; its products are bitwise symmetric --
+                // the same factors summed in the same order -- and so are the two values it writes)
+                const double v = ((pr[i][j] - t[i][j]) + (pm[i][j] - t[i][j])) / 2.;
+                a.P[(size_t)r * a.ld + c] = v;
+                if (R0 != C0) a.P[(size_t)c * a.ld + r] = v;
+            }
+        }
+}
+static inline size_t upd_solve_lds(int k) { return sizeof(double) * ((size_t)k * (k + 1) / 2 + 8); }
+
 __global__ __launch_bounds__(UT) void update_front_kernel(UpdArgs a) { update_front(a); }
 __global__ __launch_bounds__(UT) void update_back_kernel(UpdArgs a) { update_back(a); }
 __global__ __launch_bounds__(UT) void update_front_batch_kernel(const UpdArgs* __restrict__ arr)
@@ -1483,7 +1704,7 @@ __global__ __launch_bounds__(UT) void update_back_batch_kernel(const UpdArgs* __
 }
 // LDS of the two halves for a stream with m stacked rows over nc columns
 static inline size_t update_front_lds(int m) { return sizeof(double) * (2 * (size_t)m + 8); }
-static inline size_t update_back_lds(int m, int nc) { const size_t k = m > nc ? nc : m; return sizeof(double) * (k * (k + 1) / 2 + 8 + 2 * (size_t)PANEL_Q * PANEL_W); }
+static inline size_t update_back_lds(int m, int nc) { const size_t k = upd_k(m, nc); return sizeof(double) * (k * (k + 1) / 2 + 8 + 2 * (size_t)PANEL_Q * PANEL_W); }
 // The kernels with dynamic LDS are allowed the whole 160 KB once, up front: the limit is process-wide state, and the
 // stream groups of the batched filter launch concurrently from several host threads (a per-launch hipFuncSetAttribute
 // with the launch's own size could lower the limit under another thread's launch).
@@ -1493,7 +1714,8 @@ static int msckf_lds_opt_in()
         const int lim = 160 * 1024;
         const void* fns[5] = {reinterpret_cast<const void*>(feature_kernel<16>), reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
                               reinterpret_cast<const void*>(update_front_kernel), reinterpret_cast<const void*>(update_front_batch_kernel)};
-        const void* fns2[2] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel)};
+        const void* fns2[3] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel),
+                               reinterpret_cast<const void*>(upd_solve_kernel)};
         for (const void* f : fns2) {
             hipFuncAttributes at;
             hipError_t e = hipFuncGetAttributes(&at, f);
