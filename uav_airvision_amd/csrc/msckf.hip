@@ -1487,8 +1487,9 @@ __device__ __forceinline__ void update_back(const UpdArgs& a)
 // nothing else can be resident beside it; these kernels are <= 64 VGPRs each, so the front-end's kernels share the CUs.
 //   T^T = P[:, cols] H_thin^T   (n x k)      upd_tt_kernel
 //   S   = H_thin P_cc H_thin^T + s^2 I        upd_s_kernel      (rows cols[q] of T^T are exactly P_cc H_thin^T)
-//   L L^T = S;  Y = L^-1 [T | r];  dx = Y^T y_r      upd_solve_kernel
-//   P  <- sym(P - Y^T Y)  in place                     upd_p_kernel
+//   L L^T = S                                  upd_chol_kernel   (blocked, LDS)
+//   Y = L^-1 [T | r]                           upd_fsolve_kernel (a lane per right-hand side, L through the scalar cache)
+//   P  <- sym(P - Y^T Y) in place, dx = Y^T y_r   upd_p_kernel
 // fp64 MFMA is not used: on MI355X the fp64 matrix peak equals the fp64 vector peak (78.6 TFLOP/s, CDNA4 halved the
 // MI300's fp64 matrix rate), so v_mfma_f64_16x16x4 buys no throughput over v_fma_f64 and costs the fragment shuffles.
 // ================================================================================================
@@ -1577,71 +1578,130 @@ __global__ __launch_bounds__(256) void upd_s_kernel(const UpdArgs* __restrict__ 
     }
 }
 
-// Cholesky S = L L^T (packed lower triangle in LDS), Y = L^-1 [T | r_thin] (one thread per right-hand side), dx = Y^T y_r.
-__global__ __launch_bounds__(256) void upd_solve_kernel(const UpdArgs* __restrict__ arr)
+// Cholesky S = L L^T: packed lower triangle in LDS, blocked right-looking with panels of 8 columns -- the 8 x 8 diagonal
+// block is factored by one thread in registers, the panel below it one row per thread, the trailing block by a 16 x 16 thread
+// grid: three barriers per EIGHT columns (the unblocked form pays one per column, and the barrier is most of a step at
+// these sizes).  L goes back to Sbuf (row-major) for the substitution kernel, which reads it through the scalar cache.
+constexpr int CNB = 8;
+__global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict__ arr)
 {
     extern __shared__ double Lp[];
     const UpdArgs a = arr[blockIdx.x];
     if (a.m <= 0) return;
-    const int tid = threadIdx.x, n = a.n, nc = a.nc;
-    const int k = upd_k(a.m, nc);
-    double* rcol = a.W + (size_t)nc * a.ldt;
+    const int tid = threadIdx.x;
+    const int k = upd_k(a.m, a.nc);
+    auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
     for (int e = tid; e < k * k; e += 256) {
         const int r = e / k, c = e - r * k;
-        if (c <= r) Lp[r * (r + 1) / 2 + c] = a.Sbuf[(size_t)r * a.ld + c];
+        if (c <= r) at(r, c) = a.Sbuf[(size_t)r * a.ld + c];
     }
     __syncthreads();
-    // right-looking, column scaling deferred: step j subtracts a_rj a_cj / d_j from the trailing block (one barrier per column)
-    for (int j = 0; j < k; ++j) {
-        const double inv = 1.0 / Lp[j * (j + 1) / 2 + j];
-        for (int r = j + 1 + (tid >> 4); r < k; r += 16) {
-            const double lrj = Lp[r * (r + 1) / 2 + j] * inv;
-            for (int c = j + 1 + (tid & 15); c <= r; c += 16) Lp[r * (r + 1) / 2 + c] -= lrj * Lp[c * (c + 1) / 2 + j];
+    for (int j0 = 0; j0 < k; j0 += CNB) {
+        const int nb = min(CNB, k - j0), jb = j0 + nb;
+        if (tid == 0) {                                    // diagonal block: Cholesky of nb x nb in registers
+            double A[CNB][CNB];
+#pragma unroll
+            for (int i = 0; i < CNB; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) A[i][j] = (i < nb) ? at(j0 + i, j0 + j) : (i == j ? 1.0 : 0.0);
+#pragma unroll
+            for (int j = 0; j < CNB; ++j) {
+                double d = A[j][j];
+#pragma unroll
+                for (int t = 0; t < j; ++t) d -= A[j][t] * A[j][t];
+                d = sqrt(d);
+                A[j][j] = d;
+                const double inv = 1.0 / d;
+#pragma unroll
+                for (int i = j + 1; i < CNB; ++i) {
+                    double v = A[i][j];
+#pragma unroll
+                    for (int t = 0; t < j; ++t) v -= A[i][t] * A[j][t];
+                    A[i][j] = v * inv;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CNB; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) if (i < nb) at(j0 + i, j0 + j) = A[i][j];
+        }
+        __syncthreads();
+        if (jb >= k) break;
+        for (int r = jb + tid; r < k; r += 256) {          // panel: row r of L21 = A21 L11^-T
+            double x[CNB];
+#pragma unroll
+            for (int t = 0; t < CNB; ++t) x[t] = t < nb ? at(r, j0 + t) : 0.0;
+#pragma unroll
+            for (int t = 0; t < CNB; ++t) if (t < nb) {
+                double v = x[t];
+#pragma unroll
+                for (int u = 0; u < t; ++u) v -= x[u] * at(j0 + t, j0 + u);
+                x[t] = v / at(j0 + t, j0 + t);
+            }
+#pragma unroll
+            for (int t = 0; t < CNB; ++t) if (t < nb) at(r, j0 + t) = x[t];
+        }
+        __syncthreads();
+        for (int r = jb + (tid >> 4); r < k; r += 16) {    // trailing block: A22 -= L21 L21^T (lower triangle)
+            double lr[CNB];
+#pragma unroll
+            for (int t = 0; t < CNB; ++t) lr[t] = t < nb ? at(r, j0 + t) : 0.0;
+            for (int c = jb + (tid & 15); c <= r; c += 16) {
+                double v = at(r, c);
+#pragma unroll
+                for (int t = 0; t < CNB; ++t) if (t < nb) v -= lr[t] * at(c, j0 + t);
+                at(r, c) = v;
+            }
         }
         __syncthreads();
     }
     for (int e = tid; e < k * k; e += 256) {
         const int r = e / k, c = e - r * k;
-        if (c < r) Lp[r * (r + 1) / 2 + c] /= sqrt(Lp[c * (c + 1) / 2 + c]);
+        if (c <= r) a.Sbuf[(size_t)r * a.ld + c] = at(r, c);
     }
-    __syncthreads();
-    for (int j = tid; j < k; j += 256) Lp[j * (j + 1) / 2 + j] = sqrt(Lp[j * (j + 1) / 2 + j]);
-    __syncthreads();
-    // forward substitution, blocked by 8 rows: right-hand side c < n is row c of T^T (contiguous), c == n is r_thin
-    for (int c = tid; c <= n; c += 256) {
-        const double* src = c < n ? a.T + (size_t)c * a.ld : rcol;
-        double* y = c < n ? a.Kt + c : rcol;
-        const size_t st_ = c < n ? (size_t)a.ld : 1;
-        for (int i0 = 0; i0 < k; i0 += 8) {
-            double acc[8];
+}
+
+// Y = L^-1 [T | r_thin]: one LANE per right-hand side (column c < n is row c of T^T, c == n is r_thin), 64 right-hand sides
+// per single-wavefront workgroup, blocked by 8 rows.  L (written by upd_chol_kernel) is the same for every lane: it is read
+// through the constant address space, i.e. by scalar loads into SGPRs that feed v_fma_f64 directly -- no LDS, no vector
+// load per L entry -- and the workgroups of one stream spread over three CUs instead of idling 114 threads of one.
+__global__ __launch_bounds__(64) void upd_fsolve_kernel(const UpdArgs* __restrict__ arr)
+{
+    const UpdArgs a = arr[blockIdx.y];
+    if (a.m <= 0) return;
+    const int n = a.n, nc = a.nc, k = upd_k(a.m, nc);
+    if ((int)blockIdx.x * 64 > n) return;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const bool act = c <= n;
+    typedef const double __attribute__((address_space(4)))* scalar_ptr;
+    scalar_ptr L = (scalar_ptr)(a.Sbuf);
+    const int ld = a.ld;
+    double* rcol = a.W + (size_t)nc * a.ldt;
+    const double* src = (act && c < n) ? a.T + (size_t)c * ld : rcol;
+    double* y = (act && c < n) ? a.Kt + c : rcol;
+    const size_t st_ = (act && c < n) ? (size_t)ld : 1;
+    for (int i0 = 0; i0 < k; i0 += 8) {
+        double acc[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] = i0 + u < k ? src[i0 + u] : 0.0;
-            const double* Lr[8];
+        for (int u = 0; u < 8; ++u) acc[u] = (act && i0 + u < k) ? src[i0 + u] : 0.0;
+        int row[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = min(i0 + u, k - 1); Lr[u] = Lp + (size_t)i * (i + 1) / 2; }
+        for (int u = 0; u < 8; ++u) row[u] = min(i0 + u, k - 1) * ld;
 #pragma unroll 4
-            for (int q = 0; q < i0; ++q) {
-                const double yq = y[(size_t)q * st_];
+        for (int q = 0; q < i0; ++q) {
+            const double yq = act ? y[(size_t)q * st_] : 0.0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u] -= Lr[u][q] * yq;
-            }
+            for (int u = 0; u < 8; ++u) acc[u] = __builtin_fma(-L[row[u] + q], yq, acc[u]);
+        }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (i0 + u < k) {
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u < k) {
 #pragma unroll
-                    for (int w = 0; w < u; ++w) acc[u] -= Lr[u][i0 + w] * acc[w];
-                    acc[u] /= Lr[u][i0 + u];
-                    y[(size_t)(i0 + u) * st_] = acc[u];
-                }
+                for (int w = 0; w < u; ++w) acc[u] = __builtin_fma(-L[row[u] + i0 + w], acc[w], acc[u]);
+                acc[u] /= L[row[u] + i0 + u];
+                if (act) y[(size_t)(i0 + u) * st_] = acc[u];
             }
         }
-    }
-    __syncthreads();
-    for (int c = tid; c < n; c += 256) {
-        double sacc = 0;
-#pragma unroll 8
-        for (int i = 0; i < k; ++i) sacc += a.Kt[(size_t)i * a.ld + c] * rcol[i];
-        a.dx[c] = sacc;
     }
 }
 
@@ -1662,6 +1722,15 @@ __global__ __launch_bounds__(256) void upd_p_kernel(const UpdArgs* __restrict__ 
     gemm_tile64(k, r0, c0,
                 [&](int q, int r) { return r < n ? a.Kt[(size_t)q * a.ld + r] : 0.0; },
                 [&](int q, int c) { return c < n ? a.Kt[(size_t)q * a.ld + c] : 0.0; }, t);
+    if (blockIdx.x == 0) {                                   // delta_x = Y^T y_r, by the stream's first tile
+        const double* rcol = a.W + (size_t)a.nc * a.ldt;
+        for (int c = threadIdx.x; c < n; c += 256) {
+            double sacc = 0;
+#pragma unroll 8
+            for (int i = 0; i < k; ++i) sacc += a.Kt[(size_t)i * a.ld + c] * rcol[i];
+            a.dx[c] = sacc;
+        }
+    }
     const int R0 = r0 + 4 * (threadIdx.x >> 4), C0 = c0 + 4 * (threadIdx.x & 15);
     if (R0 < C0 || R0 >= n) return;
     double pr[4][4], pm[4][4];
@@ -1692,10 +1761,31 @@ static inline size_t upd_solve_lds(int k) { return sizeof(double) * ((size_t)k *
 
 __global__ __launch_bounds__(UT) void update_front_kernel(UpdArgs a) { update_front(a); }
 __global__ __launch_bounds__(UT) void update_back_kernel(UpdArgs a) { update_back(a); }
-__global__ __launch_bounds__(UT) void update_front_batch_kernel(const UpdArgs* __restrict__ arr)
+// `list` (optional): the streams to run, so that the 1024-thread workgroups exist only for the streams that really compress
+__global__ __launch_bounds__(UT) void update_front_batch_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list)
 {
-    const UpdArgs a = arr[blockIdx.x];                                 // block-uniform: lives in scalar registers
+    const UpdArgs a = arr[list ? list[blockIdx.x] : (int)blockIdx.x];  // block-uniform: lives in scalar registers
     if (a.m > 0) update_front(a);
+}
+// Streams whose stacked Jacobian is NOT compressed (upd_compress: at most 144 rows) only need the gated feature blocks
+// gathered into the transposed work matrix: a 256-thread workgroup, no QR machinery.
+__global__ __launch_bounds__(256) void upd_gather_kernel(const UpdArgs* __restrict__ arr)
+{
+    const UpdArgs a = arr[blockIdx.x];
+    if (a.m <= 0 || upd_compress(a.m, a.nc)) return;
+    __shared__ int srow[256], bstart[256];
+    const int tid = threadIdx.x, m = a.m, nc = a.nc, nb = a.n_blk;        // m <= 144, every block has at least one row
+    if (tid == 0) { int run = 0; for (int b = 0; b < nb; ++b) { bstart[b] = run; run += a.blk_len[b]; } }
+    __syncthreads();
+    if (tid < nb) { const int len = a.blk_len[tid], r0 = a.blk_row[tid], d0 = bstart[tid]; for (int r = 0; r < len; ++r) srow[d0 + r] = r0 + r; }
+    __syncthreads();
+    const size_t ldt = a.ldt;
+    for (int i = tid; i < m * nc; i += 256) {
+        const int q = i / m, row = i - q * m;
+        a.W[(size_t)q * ldt + row] = a.Hsrc[(size_t)srow[row] * a.ld + a.cols[q]];
+    }
+    double* rcol = a.W + (size_t)nc * ldt;
+    for (int row = tid; row < m; row += 256) rcol[row] = a.rsrc[srow[row]];
 }
 __global__ __launch_bounds__(UT) void update_back_batch_kernel(const UpdArgs* __restrict__ arr)
 {
@@ -1715,7 +1805,7 @@ static int msckf_lds_opt_in()
         const void* fns[5] = {reinterpret_cast<const void*>(feature_kernel<16>), reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
                               reinterpret_cast<const void*>(update_front_kernel), reinterpret_cast<const void*>(update_front_batch_kernel)};
         const void* fns2[3] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel),
-                               reinterpret_cast<const void*>(upd_solve_kernel)};
+                               reinterpret_cast<const void*>(upd_chol_kernel)};
         for (const void* f : fns2) {
             hipFuncAttributes at;
             hipError_t e = hipFuncGetAttributes(&at, f);
