@@ -325,6 +325,24 @@ def main():
     frame_ts = [[streams[s % U].frame_time(k) for s in range(S)] for k in range(F)]
     gen_s = time.time() - t_gen
 
+    # Optional CU partition (AV_FE_CUS="first:count" for the front-end's stream, AV_MSCKF_CUS for the filter's inside the
+    # library): the front-end's kernels are then confined to their compute units and the filter's latency-bound kernels
+    # never queue behind resident front-end workgroups.
+    fe_stream = None
+    if os.environ.get('AV_FE_CUS'):
+        import ctypes
+        first, count = [int(v) for v in os.environ['AV_FE_CUS'].split(':')]
+        mask = (ctypes.c_uint32 * 8)()
+        for c in range(first, min(256, first + count)):
+            mask[c >> 5] |= 1 << (c & 31)
+        hip = ctypes.CDLL('libamdhip64.so')
+        hs = ctypes.c_void_p()
+        rc_ = hip.hipExtStreamCreateWithCUMask(ctypes.byref(hs), 8, mask)
+        if rc_ != 0:
+            sys.stderr.write('bench.py: hipExtStreamCreateWithCUMask failed (%d)\n' % rc_)
+            return 4
+        fe_stream = torch.cuda.ExternalStream(hs.value, device=dev)
+        torch.cuda.set_stream(fe_stream)
     eng = FrontendEngine(cfg, n_streams=S, device=local_rank)
     flt = None
     if with_msckf:
@@ -499,6 +517,7 @@ def main():
                 'tracked_features_per_frame': n_t, 'published_features_per_frame': n_pub,
                 'lk_point_passes_per_frame': p_frame, 'algorithmic_bytes_per_frame': b_frame,
                 'frame_hbm_frac': fps / world * b_frame / 1e9 / HBM_PEAK_GBS,
+                'cu_partition': {'frontend': os.environ.get('AV_FE_CUS'), 'filter': os.environ.get('AV_MSCKF_CUS')},
             },
             'steady_state': {
                 'prerolled_frames': PRE,

@@ -12,6 +12,9 @@
 //
 // Roofline: HBM-bound streaming (level 0: w*h read + padded write; levels 1..3: 1/4, 1/16, 1/64
 // of that).  Integer arithmetic only: separable [1 4 6 4 1], (sum + 128) >> 8.
+#include <limits.h>
+#include <stdlib.h>
+
 #include "av_common.h"
 
 namespace {
@@ -64,6 +67,155 @@ __global__ __launch_bounds__(256) void pad_level0_kernel(PyrArgs a)
         out = make_uint4(o[0], o[1], o[2], o[3]);
     }
     *reinterpret_cast<uint4*>(dst + (size_t)yp * pitch + xc * 16) = out;
+}
+
+// Levels 0 AND 1 in one pass over the input image: a 128 x 32 tile of the image (+ a 2-pixel halo, reflect-101 at the image
+// border) is staged in LDS once; from it the workgroup writes its part of the padded level 0 (16-byte stores, the frame
+// parts of border tiles gathered through the reflection), filters the 64 x 16 tile of level 1 (row filter by v_dot4 into
+// u16 sums, column filter, (sum + 128) >> 8) and writes it, plus the mirror images of those level-1 pixels that lie within
+// 16 pixels of the image border (the frame of level 1).  The separate pad and first pyrDown kernels read the image and
+// re-read the padded level 0 (0.8 MB per image through L2); here every input byte is read once.
+constexpr int FT_W = 128, FT_H = 32, FT_LP = FT_W + 8;        // LDS row: columns x0-4 .. x0+131
+__global__ __launch_bounds__(256) void pyr_l0l1_kernel(PyrArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t src[(FT_H + 4) * FT_LP];
+    __shared__ __attribute__((aligned(16))) uint16_t hs[(FT_H + 4) * (FT_W / 2)];
+    __shared__ __attribute__((aligned(16))) uint8_t l1t[(FT_H / 2) * (FT_W / 2)];
+    const int w = a.g.w[0], h = a.g.h[0], pitch0 = a.g.pitch[0];
+    const int w1 = a.g.w[1], h1 = a.g.h[1], pitch1 = a.g.pitch[1];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    const int img = blockIdx.z;
+    const int s = img / a.imgs_per_stream, cam = img - s * a.imgs_per_stream;
+    const uint8_t* in = (cam == 0 ? a.img0 : a.img1) + s * a.img_stride;
+    uint8_t* base = pyr_of(a, img);
+    uint8_t* d0 = base + a.g.off[0];
+    uint8_t* d1 = base + a.g.off[1];
+    uint32_t* srcw = reinterpret_cast<uint32_t*>(src);
+
+    // ---- stage rows y0-2 .. y0+FT_H+1, columns x0-4 .. x0+131 (reflect-101 outside the image): per row eight 16-byte chunks
+    //      of the tile's own columns plus the two halo dwords ----
+    const bool al16 = ((a.img_stride & 15) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+    for (int i = tid; i < (FT_H + 4) * 10; i += 256) {
+        const int r = i / 10, j = i - r * 10;
+        const int gy = av_reflect101(y0 - 2 + r, h);
+        const uint8_t* row = in + (size_t)gy * w;
+        if (j < 8) {
+            const int gx = x0 + 16 * j;
+            uint32_t v[4];
+            if (gx + 16 <= w && al16) {
+                const uint4 q = *reinterpret_cast<const uint4*>(row + gx);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (gx + 4 * d + 4 <= w) v[d] = *reinterpret_cast<const uint32_t*>(row + gx + 4 * d);
+                    else {
+                        v[d] = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) { int x = av_reflect101(gx + 4 * d + b, w); x = min(max(x, 0), w - 1); v[d] |= (uint32_t)row[x] << (8 * b); }
+                    }
+                }
+            }
+            uint32_t* dst = srcw + r * (FT_LP / 4) + 1 + 4 * j;
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+        } else {
+            const int gx = j == 8 ? x0 - 4 : x0 + FT_W;
+            uint32_t v;
+            if (gx >= 0 && gx + 4 <= w) v = *reinterpret_cast<const uint32_t*>(row + gx);
+            else {
+                v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { int x = av_reflect101(gx + b, w); x = min(max(x, 0), w - 1); v |= (uint32_t)row[x] << (8 * b); }
+            }
+            srcw[r * (FT_LP / 4) + (j == 8 ? 0 : FT_LP / 4 - 1)] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- padded level 0: destination rows / 16-byte chunks owned by this tile (interior + its share of the frame) ----
+    {
+        const bool top = y0 == 0, bot = y0 + FT_H >= h, left = x0 == 0, right = x0 + FT_W >= w;
+        const int tw = min(FT_W, w - x0);                                 // valid interior columns (multiple of 16 or the image's tail)
+        const int nrow = FT_H + (top ? AV_PYR_BORDER : 0) + (bot ? AV_PYR_BORDER : 0);
+        const int nch_in = (tw + 15) >> 4;
+        const int nch = nch_in + (left ? 1 : 0) + (right ? (pitch0 - AV_PYR_BORDER - w + 15) / 16 : 0);
+        for (int i = tid; i < nrow * nch; i += 256) {
+            const int ri = i / nch, ci = i - ri * nch;
+            // destination row (image coordinates): the tile's own rows first, then the frame rows above / below
+            int yp;
+            if (ri < FT_H) yp = y0 + ri;
+            else if (top && ri < FT_H + AV_PYR_BORDER) yp = -(ri - FT_H + 1);
+            else yp = h + (ri - FT_H - (top ? AV_PYR_BORDER : 0));
+            if (yp >= h + AV_PYR_BORDER || (ri < FT_H && yp >= h)) continue;
+            int xd;                                                        // first destination column of the chunk
+            bool interior;
+            if (ci < nch_in) { xd = x0 + 16 * ci; interior = true; }
+            else if (left && ci == nch_in) { xd = -AV_PYR_BORDER; interior = false; }
+            else { xd = w + 16 * (ci - nch_in - (left ? 1 : 0)); interior = false; }
+            const int sy = av_reflect101(yp, h) - (y0 - 2);                // staged row of the source pixel row
+            uint32_t o[4];
+            if (interior && xd + 16 <= w) {
+                const uint32_t* p = srcw + sy * (FT_LP / 4) + ((xd - x0 + 4) >> 2);
+                o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3];
+            } else {
+                o[0] = o[1] = o[2] = o[3] = 0;
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    int x = av_reflect101(xd + b, w); x = min(max(x, 0), w - 1);
+                    o[b >> 2] |= (uint32_t)src[sy * FT_LP + (x - x0 + 4)] << (8 * (b & 3));
+                }
+            }
+            *reinterpret_cast<uint4*>(d0 + (size_t)(yp + AV_PYR_BORDER) * pitch0 + (xd + AV_PYR_BORDER)) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+
+    // ---- level 1: row filter [1 4 6 4 1] of the staged rows into u16 sums: 4 outputs per item from 16 staged bytes ----
+    for (int i = tid; i < (FT_H + 4) * (FT_W / 8); i += 256) {
+        const int r = i / (FT_W / 8), xq = i - r * (FT_W / 8);
+        const uint2 lo = *reinterpret_cast<const uint2*>(src + r * FT_LP + 8 * xq);
+        const uint2 hi = *reinterpret_cast<const uint2*>(src + r * FT_LP + 8 * xq + 8);
+        const uint32_t dx_ = lo.x, dy_ = lo.y, dz_ = hi.x, dw_ = hi.y;
+        const uint32_t t0 = __builtin_amdgcn_alignbyte(dy_, dx_, 2), t1 = dy_, t2 = __builtin_amdgcn_alignbyte(dz_, dy_, 2), t3 = dz_;
+        const uint32_t W4 = 0x04060401u;
+        const uint32_t h0 = __builtin_amdgcn_udot4(t0, W4, (dy_ >> 16) & 0xFF, false);
+        const uint32_t h1_ = __builtin_amdgcn_udot4(t1, W4, dz_ & 0xFF, false);
+        const uint32_t h2 = __builtin_amdgcn_udot4(t2, W4, (dz_ >> 16) & 0xFF, false);
+        const uint32_t h3 = __builtin_amdgcn_udot4(t3, W4, dw_ & 0xFF, false);
+        *reinterpret_cast<uint2*>(hs + r * (FT_W / 2) + 4 * xq) = make_uint2(h0 | (h1_ << 16), h2 | (h3 << 16));
+    }
+    __syncthreads();
+    // column filter: thread t -> level-1 row yo = t / 16, columns 4 xq .. 4 xq + 3 of the tile
+    if (tid < (FT_H / 2) * (FT_W / 8)) {
+        const int yo = tid >> 4, xq = tid & 15;
+        uint32_t out = 0;
+        const uint16_t* c = hs + (2 * yo) * (FT_W / 2) + 4 * xq;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = (int)c[k] + (int)c[4 * (FT_W / 2) + k] + 4 * ((int)c[(FT_W / 2) + k] + (int)c[3 * (FT_W / 2) + k]) + 6 * (int)c[2 * (FT_W / 2) + k];
+            out |= (uint32_t)((v + 128) >> 8) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(l1t + yo * (FT_W / 2) + 4 * xq) = out;
+        const int x1 = x0 / 2 + 4 * xq, y1 = y0 / 2 + yo;
+        if (x1 < w1 && y1 < h1) *reinterpret_cast<uint32_t*>(d1 + (size_t)(y1 + AV_PYR_BORDER) * pitch1 + (x1 + AV_PYR_BORDER)) = out;
+    }
+    // frame of level 1: the level-1 pixels of this tile that lie within 16 pixels of the border are mirrored outwards
+    const int X1 = x0 / 2, Y1 = y0 / 2;
+    const bool band = X1 <= AV_PYR_BORDER || X1 + FT_W / 2 >= w1 - AV_PYR_BORDER - 1 || Y1 <= AV_PYR_BORDER || Y1 + FT_H / 2 >= h1 - AV_PYR_BORDER - 1;
+    if (band) {
+        __syncthreads();
+        for (int i = tid; i < (FT_H / 2) * (FT_W / 2); i += 256) {
+            const int yo = i / (FT_W / 2), xo = i - yo * (FT_W / 2);
+            const int x1 = X1 + xo, y1 = Y1 + yo;
+            if (x1 >= w1 || y1 >= h1) continue;
+            const uint8_t v = l1t[i];
+            const int xm = (x1 >= 1 && x1 <= AV_PYR_BORDER) ? -x1 : ((x1 >= w1 - 1 - AV_PYR_BORDER && x1 <= w1 - 2) ? 2 * (w1 - 1) - x1 : INT_MIN);
+            const int ym = (y1 >= 1 && y1 <= AV_PYR_BORDER) ? -y1 : ((y1 >= h1 - 1 - AV_PYR_BORDER && y1 <= h1 - 2) ? 2 * (h1 - 1) - y1 : INT_MIN);
+            if (xm != INT_MIN) d1[(size_t)(y1 + AV_PYR_BORDER) * pitch1 + (xm + AV_PYR_BORDER)] = v;
+            if (ym != INT_MIN) d1[(size_t)(ym + AV_PYR_BORDER) * pitch1 + (x1 + AV_PYR_BORDER)] = v;
+            if (xm != INT_MIN && ym != INT_MIN) d1[(size_t)(ym + AV_PYR_BORDER) * pitch1 + (xm + AV_PYR_BORDER)] = v;
+        }
+    }
 }
 
 // level l (>= 1) from padded level l-1.
@@ -146,13 +298,23 @@ int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stri
     a.pyr_base = pyr_base; a.stream_stride = stream_stride; a.slot_stride = slot_stride;
     a.slot0 = slot0; a.slot1 = slot1; a.g = g;
     const int n_img = n_streams * imgs_per_stream;
-    {
+    const int w = g.w[0], h = g.h[0];
+    // the fused level-0 + level-1 kernel needs: dword-aligned rows, whole 32-row tiles, a last tile column that still holds the
+    // 17 pixels its frame mirrors, images large enough that a pixel is never in two mirror bands
+    const bool fused = g.levels >= 2 && (w & 15) == 0 && (h % FT_H) == 0 && h >= 64 && w >= 64 && (w % FT_W == 0 || w % FT_W >= 20) &&
+                       (img_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(img0) & 3) == 0 && (!img1 || (reinterpret_cast<uintptr_t>(img1) & 3) == 0) &&
+                       !getenv("AV_PYR_UNFUSED");
+    if (fused) {
+        dim3 grid((w + FT_W - 1) / FT_W, h / FT_H, n_img);
+        hipLaunchKernelGGL(pyr_l0l1_kernel, grid, dim3(256), 0, st, a);
+        AV_LAUNCH_CHECK();
+    } else {
         int chunks = (g.pitch[0] >> 4) * (g.h[0] + 2 * AV_PYR_BORDER);
         dim3 grid((chunks + 255) / 256, n_img);
         hipLaunchKernelGGL(pad_level0_kernel, grid, dim3(256), 0, st, a);
         AV_LAUNCH_CHECK();
     }
-    for (int l = 1; l < g.levels; ++l) {
+    for (int l = fused ? 2 : 1; l < g.levels; ++l) {
         int quads = (g.pitch[l] >> 2) * (g.h[l] + 2 * AV_PYR_BORDER);
         dim3 grid((quads + 255) / 256, n_img);
         hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, st, a, l);
