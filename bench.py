@@ -212,7 +212,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--streams', type=int, default=1024, help='independent stereo streams per GPU')
+    ap.add_argument('--streams', type=int, default=2048, help='independent stereo streams per GPU')
     ap.add_argument('--unique', type=int, default=4, help='distinct rendered streams (replicated with per-stream noise)')
     ap.add_argument('--no-stagger', action='store_true', help='start every replica at frame 0 (all filters then prune on the same frames)')
     ap.add_argument('--host-images', action='store_true', help='front-end only, images handed over as host numpy arrays every step '

@@ -160,3 +160,28 @@ def test_offset_sweep_1500_features_eight_streams_one_gpu(pool, tmp_path):
         print('  ', r)
     assert all(r['frames'] == 46 and r['filter_frames'] >= 24 for r in report)
     assert counters['prune_stream_steps'] >= 8 and counters['devbuf_growths'] == 0, counters
+
+
+def test_sweep_cli_writes_reference_format_trajectories(tmp_path):
+    """`python -m uav_airvision_amd.sweep` (the run.bat replica, run.bat:4-12): sequences x offsets -> one batch on this GPU ->
+    results/txts/output_<seq>_offset<o>.txt in the reference's line format + an ATE / RTE report per stream.  BASELINE
+    configs[3] shape on one rank (with torchrun the same command shards the pairs over the ranks)."""
+    import json
+    import subprocess
+    from uav_airvision_amd import evaluate
+    out = tmp_path / 'txts'
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    p = subprocess.run([sys.executable, '-m', 'uav_airvision_amd.sweep', '--make-synthetic', str(tmp_path / 'syn'), '--frames', '70',
+                        '--sequences', 'SYN_A', 'SYN_B', '--offsets', '0', '1', '--out', str(out)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rep = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    assert len(rep['streams']) == 4 and len(rep['report']) == 4
+    for r in rep['report']:
+        assert r['frames'] >= 28 and r['ate_rmse'] < 0.05 and r['rte_rmse'] < 0.05, r
+    for seq in ('SYN_A', 'SYN_B'):
+        for off in (0, 1):
+            tr = evaluate.load_trajectory_txt(str(out / ('output_%s_offset%d.txt' % (seq, off))))
+            assert tr.shape[1] == 8 and len(tr) >= 28
+            assert np.all(np.diff(tr[:, 0]) > 0) and abs(np.linalg.norm(tr[-1, 4:8]) - 1.0) < 1e-6

@@ -141,15 +141,28 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
                 const uint32_t C = rowc[0], L = q > 0 ? rowc[-1] : 0u, R = rowc[1];
                 const uint32_t U = rowc[-3 * PWD], D = rowc[3 * PWD];
                 const uint32_t R3 = __builtin_amdgcn_alignbyte(R, C, 3), L3 = __builtin_amdgcn_alignbyte(C, L, 1);      // p[+3], p[-3] of the four positions
+                // Packed 16-bit lanes, two pixels per register.  Any 9-arc of the 16-ring holds at least one pixel of EVERY
+                // antipodal pair, so "centre brighter than one of (p0, p8) AND than one of (p4, p12)" -- or the same for darker --
+                // is necessary for a corner (OpenCV's own first rejection tests):
+                //   bright: min(max(d0, d8), max(d4, d12)) > t     dark: max(min(d0, d8), min(d4, d12)) < -t
+                typedef short av_s2 __attribute__((ext_vector_type(2)));
+                auto half = [](uint32_t x, int hi) -> av_s2 { return __builtin_bit_cast(av_s2, __builtin_amdgcn_perm(0, x, hi ? 0x0C030C02u : 0x0C010C00u)); };
+                const av_s2 tt = {(short)t, (short)t}, zz = {0, 0};
+                uint32_t fl[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const av_s2 c = half(C, hf);
+                    const av_s2 d0 = c - half(D, hf), d8 = c - half(U, hf), d4 = c - half(R3, hf), d12 = c - half(L3, hf);
+                    const av_s2 mb = __builtin_elementwise_min(__builtin_elementwise_max(d0, d8), __builtin_elementwise_max(d4, d12));
+                    const av_s2 md = __builtin_elementwise_max(__builtin_elementwise_min(d0, d8), __builtin_elementwise_min(d4, d12));
+                    const av_s2 val = __builtin_elementwise_max(mb, zz - md);
+                    fl[hf] = __builtin_bit_cast(uint32_t, tt - val);             // negative (bit 15 of its half set) iff val > t
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int pc = 4 * q + k, x = x0 - 4 + pc;
-                    const int v = (int)((C >> (8 * k)) & 0xFF);
-                    const int d0 = v - (int)((D >> (8 * k)) & 0xFF), d4 = v - (int)((R3 >> (8 * k)) & 0xFF);
-                    const int d8 = v - (int)((U >> (8 * k)) & 0xFF), d12 = v - (int)((L3 >> (8 * k)) & 0xFF);
-                    const int nb = (d0 > t) + (d4 > t) + (d8 > t) + (d12 > t);
-                    const int nd = (d0 < -t) + (d4 < -t) + (d8 < -t) + (d12 < -t);
-                    cf[k] = (nb >= 2 || nd >= 2) && pc >= 3 && pc <= TW + 4 && x >= 3 && x < a.w - 3;
+                    const bool hit = (fl[k >> 1] >> (15 + 16 * (k & 1))) & 1u;
+                    cf[k] = hit && pc >= 3 && pc <= TW + 4 && x >= 3 && x < a.w - 3;
                 }
             }
         }
