@@ -33,12 +33,18 @@ sys.path.insert(0, ROOT)
 W_IMG, H_IMG = 752, 480
 LK_BYTES_PER_POINT_PASS = 4 * 2 * 289 + 25          # L=4 levels x (I + J window of 17x17) + point I/O
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/s spec
-# Memory-side traffic of lk_track_g16_kernel per point pass, from rocprofv3 PMC passes of this same command
-# (profiles/r01/pmc_frontend_s64_lk_g16_summary.json: FETCH_SIZE 68,263 KB and WRITE_SIZE 295 KB per launch of 19,200
-# point passes at 64 streams), corrected as MI355X_MICROARCH.md "HBM" prescribes for gfx950 (FETCH_SIZE x 2;
-# WRITE_SIZE exact).  The x2 rule is calibrated for 16-B/lane streams; this kernel stages 32-byte row segments, so
-# read it as an upper bound (uncorrected: 3.7 KB per point pass against 2.3 KB algorithmic).
-LK_TRAFFIC_BYTES_PER_POINT_PASS = (2 * 68263.08 + 295.15) * 1024 / 19200
+# rocprofv3 PMC passes of `bench.py --frontend-only --streams 64` (profiles/r02/pmc_frontend_s64_summary.json, collected by
+# profiles/r02/collect_pmc.sh: SQ block, FETCH_SIZE and WRITE_SIZE in three separate passes), per lk_track_g16_kernel launch
+# of 64 streams = 19,200 point passes:
+#   FETCH_SIZE 65,090.9 KB, WRITE_SIZE 264.3 KB (memory side of L2), SQ_INSTS_VALU 36,257,290 wave-instructions.
+# Traffic is corrected as MI355X_MICROARCH.md "HBM" prescribes for gfx950 (FETCH_SIZE x 2; WRITE_SIZE exact).  The x2 rule is
+# calibrated for 16-B/lane streams; this kernel stages its tiles with 4-byte lane loads, and the RAW figure (65 MB) is already
+# the size of the two pyramids a launch touches (64 streams x 2 x 560 KB = 72 MB): read the corrected value as an upper bound.
+LK_PMC_STREAMS = 64
+LK_TRAFFIC_BYTES_PER_LAUNCH_S64 = (2 * 65090.9 + 264.3) * 1024
+LK_VALU_INSTS_PER_LAUNCH_S64 = 36257290.0
+VALU_CYCLES_PER_WAVE_INST = 2.0                     # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
+N_SIMD, CLOCK_HZ = 1024, 2.4e9
 
 
 PREROLL_FULL = 24          # frames until every filter has 20 camera states and has pruned at least once (19 + margin)
@@ -529,12 +535,18 @@ def main():
             'roofline': {
                 'bound': 'hbm', 'kernel': 'lk_track_g16_kernel<15>',
                 'achieved': lk_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': lk_gbs / HBM_PEAK_GBS,
-                'traffic': LK_TRAFFIC_BYTES_PER_POINT_PASS * S * p_frame / 5.0,
-                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r01/pmc_frontend_s64_lk_g16_summary.json, FETCH x2 per MI355X_MICROARCH.md',
-                'note': 'lk_track_g16_kernel is VALU-issue bound (PMC: ~1,400 VALU instructions per point pass, 32% of wave cycles '
-                        'waiting on an instruction, LDS 2% of instructions); its tiles come from L2/Infinity Cache. The HBM fraction is '
-                        'reported because the path class is byte/integer work. In the complete path the span also contains the '
-                        'higher-priority filter kernels that preempt it.',
+                'traffic': LK_TRAFFIC_BYTES_PER_LAUNCH_S64 * S / LK_PMC_STREAMS,
+                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r02/pmc_frontend_s64_summary.json, FETCH x2 per '
+                                  'MI355X_MICROARCH.md; scaled from 64 streams per launch to %d' % S,
+                # the kernel is VALU-issue bound: instructions issued / what the chip's 1,024 SIMDs could issue in the launch's duration
+                'valu_issue_frac': ((LK_VALU_INSTS_PER_LAUNCH_S64 * S / LK_PMC_STREAMS) * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * CLOCK_HZ) / (lk_avg_ms * 1e-3)) if lk_avg_ms > 0 else None,
+                'valu_issue_frac_frontend_only': ((LK_VALU_INSTS_PER_LAUNCH_S64 * S / LK_PMC_STREAMS) * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * CLOCK_HZ) /
+                                                  (timing_fe['lk'][0] / max(timing_fe['lk'][1], 1) * 1e-3)) if timing_fe else None,
+                'note': 'lk_track_g16_kernel is VALU-issue bound (PMC: 36.3 M VALU wave-instructions per launch of 19,200 point passes, 38% of wave '
+                        'cycles waiting on an instruction, LDS 2% of instructions); its tiles come from L2/Infinity Cache. The HBM fraction is '
+                        'reported because the path class is byte/integer work; valu_issue_frac (2 cycles per wave64 instruction, 1,024 SIMDs at '
+                        '2.4 GHz) is the bound that binds. In the complete path the span also contains the higher-priority filter kernels '
+                        'that preempt it.',
                 'avg_launch_ms': lk_avg_ms, 'launches': lk_n, 'algorithmic_bytes_per_launch': lk_bytes_per_launch,
                 # same kernel, same inputs, timed in the front-end-only loop that follows (no filter kernels sharing the GPU)
                 'avg_launch_ms_frontend_only': (timing_fe['lk'][0] / max(timing_fe['lk'][1], 1)) if timing_fe else None,

@@ -183,6 +183,18 @@ __device__ __forceinline__ int mad24(int a, int b, int c)
     return r;
 }
 
+// 16 x 16 -> 32-bit multiply-add on selected halves: the x and y derivative of a pixel share one register (|Ix|, |Iy| <= 4080,
+// |J - I| <= 8160 all fit 16 bits), which is what brings the kernel under 96 VGPRs
+template <int HA, int HB>
+__device__ __forceinline__ int mad16(uint32_t a, uint32_t b, int c)
+{
+    int r;
+    if (HA == 0 && HB == 0) asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else if (HA == 0 && HB == 1) asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[0,1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // The Newton iteration's version for five window columns c0..c0+4 of this lane's J row (16 bytes in T0..T3): byte pairs by
 // v_perm, then as above with a per-column accumulator seed (rounding term minus the I sample):
 //   d_i = ((J[c], J[c+1]) . wtop + below(...) . wbot + seed_i) >> 9
@@ -300,7 +312,8 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
         wave_lds_sync();
 
         // ---- this lane's row of the I patch and of the Scharr patches: staged rows r..r+2, 18 bytes of each -------------
-        int iv[WIN], ixv[WIN], iyv[WIN];
+        int iv[WIN];
+        uint32_t ixy[WIN];                        // (Ix | Iy << 16) per window column
         int a11 = 0, a12 = 0, a22 = 0;
         {
             // staged byte index of window column c is c+1.  E[t][k] = (byte 2k | byte 2k+1 << 16) of staged row r+t; the window
@@ -366,15 +379,18 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
             const int rnd_i = 1 << (W_BITS - 6), rnd_d = 1 << (W_BITS - 1);      // rounding terms, one register each
 #pragma unroll
             for (int c = 0; c < WIN; c += 5) {
+                int ix_[5], iy_[5];
                 bilin5_seed(px[c], px[c + 1], px[c + 2], px[c + 3], px[c + 4], wtop, wbot, rnd_i, iv[c], iv[c + 1], iv[c + 2], iv[c + 3], iv[c + 4]);
-                bilin5<W_BITS>(gxp[c], gxp[c + 1], gxp[c + 2], gxp[c + 3], gxp[c + 4], wtop, wbot, rnd_d, ixv[c], ixv[c + 1], ixv[c + 2], ixv[c + 3], ixv[c + 4]);
-                bilin5<W_BITS>(gyp[c], gyp[c + 1], gyp[c + 2], gyp[c + 3], gyp[c + 4], wtop, wbot, rnd_d, iyv[c], iyv[c + 1], iyv[c + 2], iyv[c + 3], iyv[c + 4]);
+                bilin5<W_BITS>(gxp[c], gxp[c + 1], gxp[c + 2], gxp[c + 3], gxp[c + 4], wtop, wbot, rnd_d, ix_[0], ix_[1], ix_[2], ix_[3], ix_[4]);
+                bilin5<W_BITS>(gyp[c], gyp[c + 1], gyp[c + 2], gyp[c + 3], gyp[c + 4], wtop, wbot, rnd_d, iy_[0], iy_[1], iy_[2], iy_[3], iy_[4]);
+#pragma unroll
+                for (int u = 0; u < 5; ++u) ixy[c + u] = __builtin_amdgcn_perm((uint32_t)iy_[u], (uint32_t)ix_[u], 0x05040100u);
             }
 #pragma unroll
             for (int c = 0; c < WIN; ++c) {
-                a11 = mad24(ixv[c], ixv[c], a11);
-                a12 = mad24(ixv[c], iyv[c], a12);
-                a22 = mad24(iyv[c], iyv[c], a22);
+                a11 = mad16<0, 0>(ixy[c], ixy[c], a11);
+                a12 = mad16<0, 1>(ixy[c], ixy[c], a12);
+                a22 = mad16<1, 1>(ixy[c], ixy[c], a22);
             }
             if (!rowact) { a11 = 0; a12 = 0; a22 = 0; }
         }
@@ -436,8 +452,8 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
             int b1 = 0, b2 = 0;
 #pragma unroll
             for (int c = 0; c < WIN; ++c) {
-                b1 = mad24(df[c], ixv[c], b1);
-                b2 = mad24(df[c], iyv[c], b2);
+                b1 = mad16<0, 0>((uint32_t)df[c], ixy[c], b1);
+                b2 = mad16<0, 1>((uint32_t)df[c], ixy[c], b2);
             }
             if (!rowact) { b1 = 0; b2 = 0; }
             const float fb1 = (float)(row_sum16_exact(b1) * FLT_SCALE_D);
@@ -461,12 +477,9 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
     }
 }
 
-// Register budgets of the same body: 111 VGPRs fit 4 waves per SIMD without spills; 5 and 6 waves per SIMD spill 9 / 23
-// setup values to scratch.  The kernel is VALU-issue bound with part of its wave cycles waiting on an instruction, so the
-// extra waves can pay; AV_LK_OCC selects the build for A/B runs (default: the fastest measured).
+// 96 VGPRs: 5 waves per SIMD without spills (the kernel is VALU-issue bound: 4 -> 5 waves bought 1 %, a 6-wave build with
+// 11 spilled values lost 5 %).
 template <int WIN> __global__ __launch_bounds__(256, 4) void lk_track_g16_kernel(LKArgs a) { lk_track_g16_body<WIN, 4>(a); }
-template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_occ5_kernel(LKArgs a) { lk_track_g16_body<WIN, 5>(a); }
-template <int WIN> __global__ __launch_bounds__(256, 6) void lk_track_g16_occ6_kernel(LKArgs a) { lk_track_g16_body<WIN, 6>(a); }
 
 }  // namespace
 
@@ -486,10 +499,7 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
     a.max_iter = p.max_iter; a.eps2 = p.eps2; a.min_eig = p.min_eig;
     if (launch_pts > cap) launch_pts = cap;
     dim3 grid((launch_pts + 15) / 16, n_set);
-    static const int occ = [] { const char* e = getenv("AV_LK_OCC"); return e ? atoi(e) : 4; }();
-    if (occ == 5) hipLaunchKernelGGL(lk_track_g16_occ5_kernel<15>, grid, dim3(256), 0, st, a);
-    else if (occ == 6) hipLaunchKernelGGL(lk_track_g16_occ6_kernel<15>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
