@@ -104,7 +104,7 @@ struct LKParams {
 };
 int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride, int n_set, const PyrGeom& g,
                  const float* prev, float* next, uint8_t* status, const int* count, int cap, int launch_pts,
-                 const LKParams& p, hipStream_t st);
+                 const LKParams& p, hipStream_t st, const int* index = nullptr);
 
 // fast.hip
 int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, int border, const uint8_t* mask, int64_t mask_stride,

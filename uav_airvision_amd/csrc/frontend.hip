@@ -63,6 +63,7 @@ struct FeDev {
     // candidates for new features
     uint32_t* cand_key; float* cand_p0; float* cand_init; float* cand_p1; uint8_t* cand_st; float* cand_back; uint8_t* cand_st2;
     uint8_t* cand_inl; int* cand_off; int* cand_count;
+    int* r1_list; int* r2_list; int* r1_count; int* r2_count;      // lazy candidate matching: indices matched in round 1 / round 2
     // output
     long long* out_ids; double* out_uv; int* out_n;
     int* counters;
@@ -103,6 +104,8 @@ __device__ __forceinline__ void stereo_init(const FeDev& d, float x, float y, fl
 }
 
 // stereo_matcher.py:75-113
+constexpr int CAND_R1 = 5;      // candidates of a cell matched in round 1 (grid_min = 3 in the reference: + 2 spares)
+
 __device__ __forceinline__ bool stereo_gate(const FeDev& d, float p0x, float p0y, float inx, float iny, float p1x, float p1y,
                                             uint8_t st, float bx, float by)
 {
@@ -256,6 +259,19 @@ __global__ __launch_bounds__(256) void select_kernel(FeDev d)
     }
     __syncthreads();
     for (int c = threadIdx.x; c <= d.C; c += 256) d.cand_off[s * (d.C + 1) + c] = off[c];
+    // Round 1 of the stereo matching (see cand_round2_kernel): the first R1 candidates of every cell, all of them on the first frame
+    {
+        __shared__ int r1n;
+        if (threadIdx.x == 0) r1n = 0;
+        __syncthreads();
+        for (int c = threadIdx.x; c < d.C; c += 256) {
+            const int take = first ? cnt[c] : min(cnt[c], CAND_R1);
+            const int base = atomicAdd(&r1n, take);                     // order of the list is irrelevant: results are written by index
+            for (int r = 0; r < take; ++r) d.r1_list[(size_t)s * d.CC + base + r] = off[c] + r;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) d.r1_count[s] = r1n;
+    }
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int c = wv; c < d.C; c += 4) {
@@ -289,6 +305,41 @@ __global__ __launch_bounds__(256) void select_kernel(FeDev d)
         d.cand_p1[2 * o] = ix; d.cand_p1[2 * o + 1] = iy;
         d.cand_back[2 * o] = x; d.cand_back[2 * o + 1] = y;
     }
+}
+
+// ---- G6: lazy stereo matching of the candidates.  feature_adder.py:80-108 matches every candidate (up to grid_max per
+// cell) and then keeps, per cell, the grid_min inliers of highest response.  Candidates are sorted by response inside their
+// cell, so once the first R1 of a cell hold grid_min inliers the rest of the cell cannot change the result: round 1 matches the
+// first R1 = grid_min + 2 candidates of every cell, this kernel gates them and lists for round 2 the remaining candidates of
+// the (rare) cells that are still short.  Same ids, same points, ~3x fewer candidate LK passes at grid_max = 15.
+__global__ __launch_bounds__(256) void cand_round2_kernel(FeDev d)
+{
+    __shared__ int r2n;
+    const int s = blockIdx.x;
+    const int* coff = d.cand_off + s * (d.C + 1);
+    const bool first = d.first_frame[s] != 0;
+    if (threadIdx.x == 0) r2n = 0;
+    __syncthreads();
+    for (int c = threadIdx.x; c < d.C; c += 256) {
+        const int b = coff[c], e = coff[c + 1];
+        const int r1 = first ? (e - b) : min(e - b, CAND_R1);
+        int inl = 0;
+        for (int i = b; i < b + r1; ++i) {
+            const size_t o = (size_t)s * d.CC + i;
+            const bool ok = stereo_gate(d, d.cand_p0[2 * o], d.cand_p0[2 * o + 1], d.cand_init[2 * o], d.cand_init[2 * o + 1],
+                                        d.cand_p1[2 * o], d.cand_p1[2 * o + 1], d.cand_st[o], d.cand_back[2 * o], d.cand_back[2 * o + 1]);
+            d.cand_inl[o] = ok ? 1 : 0;
+            inl += ok;
+        }
+        const bool more = inl < d.gmin && b + r1 < e;
+        for (int i = b + r1; i < e; ++i) d.cand_inl[(size_t)s * d.CC + i] = more ? 2 : 0;      // 2 = matched in round 2, gated by finalize
+        if (more) {
+            const int base = atomicAdd(&r2n, e - b - r1);
+            for (int i = b + r1; i < e; ++i) d.r2_list[(size_t)s * d.CC + base + (i - b - r1)] = i;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) d.r2_count[s] = r2n;
 }
 
 __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* k, int n)
@@ -331,10 +382,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(FeDev d, int par)
     const int* coff = d.cand_off + s * (d.C + 1);
     const int nxt = par ^ 1;
 
-    // A. stereo gate of every candidate
+    // A. stereo gate of the candidates matched in round 2 (round 1 was gated by cand_round2_kernel; 0 = never needed)
     for (int i = threadIdx.x; i < ncand; i += 256) {
         const size_t o = (size_t)s * d.CC + i;
-        d.cand_inl[o] = stereo_gate(d, d.cand_p0[2 * o], d.cand_p0[2 * o + 1], d.cand_init[2 * o], d.cand_init[2 * o + 1],
+        if (d.cand_inl[o] == 2) d.cand_inl[o] = stereo_gate(d, d.cand_p0[2 * o], d.cand_p0[2 * o + 1], d.cand_init[2 * o], d.cand_init[2 * o + 1],
                                     d.cand_p1[2 * o], d.cand_p1[2 * o + 1], d.cand_st[o], d.cand_back[2 * o], d.cand_back[2 * o + 1]) ? 1 : 0;
     }
     for (int c = threadIdx.x; c < d.C; c += 256) trk_n[c] = 0;
@@ -650,11 +701,21 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(select_kernel, dim3(S), dim3(256), sizeof(int) * (2 * d.C + 1), st, d);
       AV_LAUNCH_CHECK(); }
-    const int cand_launch = any_first ? d.CC : d.C * d.gmax;
+    const int r1_launch = any_first ? d.CC : d.C * (d.gmax < CAND_R1 ? d.gmax : CAND_R1);
     { Span sp(fe, 1, st);
-      if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.cand_p0, d.cand_p1, d.cand_st, d.cand_count, d.CC, cand_launch, fe->lk, st))) return rc; }
+      if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.cand_p0, d.cand_p1, d.cand_st, d.r1_count, d.CC, r1_launch, fe->lk, st, d.r1_list))) return rc; }
     { Span sp(fe, 1, st);
-      if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.cand_count, d.CC, cand_launch, fe->lk, st))) return rc; }
+      if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.r1_count, d.CC, r1_launch, fe->lk, st, d.r1_list))) return rc; }
+    { Span sp(fe, 3, st);
+      hipLaunchKernelGGL(cand_round2_kernel, dim3(S), dim3(256), 0, st, d);
+      AV_LAUNCH_CHECK(); }
+    if (d.gmax > CAND_R1) {                       // round 2: the rest of the cells that are still short of inliers (usually none)
+        const int r2_launch = d.C * (d.gmax - CAND_R1);
+        { Span sp(fe, 1, st);
+          if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.cand_p0, d.cand_p1, d.cand_st, d.r2_count, d.CC, r2_launch, fe->lk, st, d.r2_list))) return rc; }
+        { Span sp(fe, 1, st);
+          if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.r2_count, d.CC, r2_launch, fe->lk, st, d.r2_list))) return rc; }
+    }
     size_t fin_lds = sizeof(unsigned long long) * d.NSORT + sizeof(int) * (2 * d.C * d.gmin + 2 * d.C + 3 * (d.C + 1) + 4);
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(finalize_kernel, dim3(S), dim3(256), fin_lds, st, d, par);
@@ -730,6 +791,7 @@ AV_EXPORT int av_frontend_create(const av_frontend_config* cfg, int n_streams, i
     A(d.cand_key, (size_t)S * d.CC) A(d.cand_p0, 2 * (size_t)S * d.CC) A(d.cand_init, 2 * (size_t)S * d.CC) A(d.cand_p1, 2 * (size_t)S * d.CC)
     A(d.cand_st, (size_t)S * d.CC) A(d.cand_back, 2 * (size_t)S * d.CC) A(d.cand_st2, (size_t)S * d.CC) A(d.cand_inl, (size_t)S * d.CC)
     A(d.cand_off, S * (C + 1))
+    A(d.r1_list, (size_t)S * d.CC) A(d.r2_list, (size_t)S * d.CC) A(d.r1_count, S) A(d.r2_count, S)
     A(d.out_ids, S * d.MAXF) A(d.out_uv, 4 * S * d.MAXF) A(d.out_n, S)
     // per-step zeroed counters in one region: trk_count, sv_count, cur_count, cand_count, cell_count, counters
     {

@@ -50,6 +50,7 @@ struct LKArgs {
     float* next;
     uint8_t* status;
     const int* count;
+    const int* index;           // optional [n_set][cap]: point j of set s is index[s*cap + j] (a subset of the point arrays)
     int cap;
     int max_iter;
     double eps2, min_eig;
@@ -248,9 +249,10 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
     const int r = threadIdx.x & 15;                 // window row owned by this lane (row 15 only feeds row 14)
     uint32_t* tile = tile_all[g];
     const int s = blockIdx.y;
-    const int pidx = blockIdx.x * 16 + g;
+    const int slot = blockIdx.x * 16 + g;
     const int n = min(a.count[s], a.cap);
-    if (pidx >= n) return;                          // uniform per 16-lane group
+    if (slot >= n) return;                          // uniform per 16-lane group
+    const int pidx = a.index ? a.index[(size_t)s * a.cap + slot] : slot;
 
     const uint8_t* PI = a.pyrI + s * a.stream_stride;
     const uint8_t* PJ = a.pyrJ + s * a.stream_stride;
@@ -485,7 +487,7 @@ template <int WIN> __global__ __launch_bounds__(256, 4) void lk_track_g16_kernel
 
 int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride, int n_set, const PyrGeom& g,
                  const float* prev, float* next, uint8_t* status, const int* count, int cap, int launch_pts,
-                 const LKParams& p, hipStream_t st)
+                 const LKParams& p, hipStream_t st, const int* index)
 {
     if (n_set <= 0 || launch_pts <= 0) return AV_OK;
     if (p.win != 15) {
@@ -495,7 +497,7 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
     if (p.win + 1 > AV_PYR_BORDER) { av_set_error("av_lk_track: window exceeds pyramid frame"); return AV_E_INVALID; }
     LKArgs a;
     a.pyrI = pyrI; a.pyrJ = pyrJ; a.stream_stride = stream_stride; a.g = g;
-    a.prev = prev; a.next = next; a.status = status; a.count = count; a.cap = cap;
+    a.prev = prev; a.next = next; a.status = status; a.count = count; a.index = index; a.cap = cap;
     a.max_iter = p.max_iter; a.eps2 = p.eps2; a.min_eig = p.min_eig;
     if (launch_pts > cap) launch_pts = cap;
     dim3 grid((launch_pts + 15) / 16, n_set);
@@ -524,5 +526,5 @@ AV_EXPORT int av_lk_track(const uint8_t* pyrI_dev, const uint8_t* pyrJ_dev, int6
     p.eps2 = e * e;
     p.min_eig = min_eig_threshold;
     return av_launch_lk(pyrI_dev, pyrJ_dev, pyr_stride, n_set, av_make_geom(lay), prev_dev, next_dev, status_dev,
-                        count_dev, cap, cap, p, (hipStream_t)stream);
+                        count_dev, cap, cap, p, (hipStream_t)stream, nullptr);
 }
