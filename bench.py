@@ -491,15 +491,18 @@ def main():
     n_t = float(np.mean([c['before_tracking'] for c in cnts]))
     n_trk = float(np.mean([c['after_tracking'] for c in cnts]))
     n_cand = float(np.mean([c['n_candidates'] for c in cnts]))
+    mc = [eng.read_match_counts(s) for s in range(0, S, max(1, S // 64))]          # a sample of the streams
+    n_match1, n_match2 = float(np.mean([m[0] for m in mc])), float(np.mean([m[1] for m in mc]))
     n_pub = float(np.mean([len(f[0]) for f in feats]))
     # counter reduction is the only end-of-run exchange (no data-path collective)
-    n_t, n_trk, n_cand, n_pub = [float(v) / world for v in shard.sum_over_ranks([n_t, n_trk, n_cand, n_pub])]
+    n_t, n_trk, n_cand, n_pub, n_match1, n_match2 = [float(v) / world for v in shard.sum_over_ranks([n_t, n_trk, n_cand, n_pub, n_match1, n_match2])]
 
     fps = world * S * K / elapsed
-    b_frame, p_frame = frame_bytes(n_t, n_trk, n_cand)
+    b_frame, p_frame = frame_bytes(n_t, n_trk, n_match1 + n_match2)      # LK point passes actually run (lazy candidate matching)
     lk_ms, lk_n = timing['lk']
     lk_avg_ms = lk_ms / max(lk_n, 1)
-    lk_bytes_per_launch = S * p_frame * LK_BYTES_PER_POINT_PASS / 5.0       # 5 LK launches per step
+    lk_launches_per_step = lk_n / float(K) if lk_n else 5.0                 # temporal, stereo fwd/bwd, candidates round 1 fwd/bwd (+ round 2)
+    lk_bytes_per_launch = S * p_frame * LK_BYTES_PER_POINT_PASS / lk_launches_per_step
     lk_gbs = lk_bytes_per_launch / (lk_avg_ms * 1e-3) / 1e9 if lk_avg_ms > 0 else 0.0
 
     if rank == 0:
@@ -522,6 +525,7 @@ def main():
                                 if stagger else '; all filters start at step 0, so all of them prune on the same steps (lock-step load)'),
                 'tracked_features_per_frame': n_t, 'published_features_per_frame': n_pub,
                 'lk_point_passes_per_frame': p_frame, 'algorithmic_bytes_per_frame': b_frame,
+                'candidates_per_frame': n_cand, 'candidates_stereo_matched_per_frame': [n_match1, n_match2],
                 'frame_hbm_frac': fps / world * b_frame / 1e9 / HBM_PEAK_GBS,
                 'cu_partition': {'frontend': os.environ.get('AV_FE_CUS'), 'filter': os.environ.get('AV_MSCKF_CUS')},
             },

@@ -176,6 +176,10 @@ int av_frontend_read_grid(av_frontend* fe, int stream_idx, int64_t* ids, int32_t
  * adder): [before_tracking, after_tracking, after_matching, n_fast_corners, n_candidates, n_new,
  * n_published, overflow_flags].  Synchronises. */
 int av_frontend_read_counters(av_frontend* fe, int stream_idx, int32_t out[8], void* stream);
+/* New-feature candidates are stereo-matched lazily (feature_adder.py:80-108 matches all of them and keeps the grid_min
+ * best inliers per cell; the first grid_min + 2 candidates of a cell decide that unless too few of them are inliers):
+ * [candidates matched in round 1, in round 2] of the last step, i.e. the LK point passes actually run.  Synchronises. */
+int av_frontend_read_match_counts(av_frontend* fe, int stream_idx, int32_t out[2], void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MSCKF back-end: the batched small-dense fp64 linear algebra of MSCKF.feature_callback

@@ -69,6 +69,7 @@ SIGNATURES = {
     'av_frontend_read_features_end': (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
     'av_frontend_read_grid': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64), _P]),
     'av_frontend_read_counters': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32 * 8), _P]),
+    'av_frontend_read_match_counts': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32 * 2), _P]),
     'av_msckf_create': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(_P)]),
     'av_msckf_destroy': (None, [_P]),
     'av_msckf_ld': (C.c_int, [_P]),

@@ -1007,6 +1007,18 @@ AV_EXPORT int av_frontend_read_grid(av_frontend* fe, int stream_idx, int64_t* id
     return AV_OK;
 }
 
+// [candidates matched in round 1, in round 2] of the last step for one stream (the lazy stereo matching of
+// cand_round2_kernel): the LK point passes actually run for new-feature candidates.  Synchronises.
+AV_EXPORT int av_frontend_read_match_counts(av_frontend* fe, int stream_idx, int32_t out[2], void* stream)
+{
+    if (!fe || !out || stream_idx < 0 || stream_idx >= fe->d.S) { av_set_error("av_frontend_read_match_counts: bad arguments"); return AV_E_INVALID; }
+    AV_HIP(hipSetDevice(fe->device));
+    AV_HIP(hipStreamSynchronize((hipStream_t)stream));
+    AV_HIP(hipMemcpy(out, fe->d.r1_count + stream_idx, sizeof(int), hipMemcpyDeviceToHost));
+    AV_HIP(hipMemcpy(out + 1, fe->d.r2_count + stream_idx, sizeof(int), hipMemcpyDeviceToHost));
+    return AV_OK;
+}
+
 AV_EXPORT int av_frontend_read_counters(av_frontend* fe, int stream_idx, int32_t out[8], void* stream)
 {
     if (!fe || stream_idx < 0 || stream_idx >= fe->d.S || !out) { av_set_error("av_frontend_read_counters: bad arguments"); return AV_E_INVALID; }

@@ -178,6 +178,13 @@ class FrontendEngine(object):
             N.check(N.lib().av_frontend_read_counters(self._h, int(stream), C.byref(out), self._stream()))
         return dict(zip(COUNTER_NAMES, [int(v) for v in out]))
 
+    def read_match_counts(self, stream=0):
+        """(candidates stereo-matched in round 1, in round 2) of the last step (lazy matching, airvision.h)."""
+        out = (C.c_int32 * 2)()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_frontend_read_match_counts(self._h, int(stream), C.byref(out), self._stream()))
+        return int(out[0]), int(out[1])
+
     def enable_timing(self, max_spans):
         """Bracket every launch group with HIP events on the step's stream (bench roofline leg)."""
         N.check(N.lib().av_frontend_enable_timing(self._h, int(max_spans)))
