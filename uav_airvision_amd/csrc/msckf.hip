@@ -880,6 +880,7 @@ struct UpdArgs {
     double obs_noise;
     int m;                                       // total stacked rows
     double* Sbuf;                                // batched back end: S = H P H^T + s^2 I, [k][ld] (lower triangle used)
+    int mode;                                    // batched back end: 0 = QR / Cholesky pipeline, 1 = information form (upd_info_kernel)
 };
 
 constexpr int UT = 1024;
@@ -1530,7 +1531,7 @@ __device__ __forceinline__ void gemm_tile64(int Q, int r0, int c0, FA loadA, FB 
 __global__ __launch_bounds__(256) void upd_tt_kernel(const UpdArgs* __restrict__ arr, int tiles_k)
 {
     const UpdArgs a = arr[blockIdx.y];
-    if (a.m <= 0) return;
+    if (a.m <= 0 || a.mode != 0) return;
     const int k = upd_k(a.m, a.nc), n = a.n;
     const int r0 = (blockIdx.x / tiles_k) * GT, c0 = (blockIdx.x % tiles_k) * GT;      // rows: state index, columns: stacked row
     if (r0 >= n || c0 >= k) return;
@@ -1552,7 +1553,7 @@ __global__ __launch_bounds__(256) void upd_tt_kernel(const UpdArgs* __restrict__
 __global__ __launch_bounds__(256) void upd_s_kernel(const UpdArgs* __restrict__ arr)
 {
     const UpdArgs a = arr[blockIdx.y];
-    if (a.m <= 0) return;
+    if (a.m <= 0 || a.mode != 0) return;
     const int k = upd_k(a.m, a.nc);
     int tr = (int)((sqrtf(8.f * blockIdx.x + 1.f) - 1.f) * 0.5f);              // triangular tile index -> (tr, tc), tc <= tr
     while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
@@ -1587,7 +1588,7 @@ __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict
 {
     extern __shared__ double Lp[];
     const UpdArgs a = arr[blockIdx.x];
-    if (a.m <= 0) return;
+    if (a.m <= 0 || a.mode != 0) return;
     const int tid = threadIdx.x;
     const int k = upd_k(a.m, a.nc);
     auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
@@ -1668,7 +1669,7 @@ __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict
 __global__ __launch_bounds__(64) void upd_fsolve_kernel(const UpdArgs* __restrict__ arr)
 {
     const UpdArgs a = arr[blockIdx.y];
-    if (a.m <= 0) return;
+    if (a.m <= 0 || a.mode != 0) return;
     const int n = a.n, nc = a.nc, k = upd_k(a.m, nc);
     if ((int)blockIdx.x * 64 > n) return;
     const int c = blockIdx.x * 64 + threadIdx.x;
@@ -1710,7 +1711,7 @@ __global__ __launch_bounds__(64) void upd_fsolve_kernel(const UpdArgs* __restric
 __global__ __launch_bounds__(256) void upd_p_kernel(const UpdArgs* __restrict__ arr)
 {
     const UpdArgs a = arr[blockIdx.y];
-    if (a.m <= 0) return;
+    if (a.m <= 0 || a.mode != 0) return;
     const int n = a.n, k = upd_k(a.m, a.nc);
     int tr = (int)((sqrtf(8.f * blockIdx.x + 1.f) - 1.f) * 0.5f);
     while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
@@ -1759,6 +1760,162 @@ __global__ __launch_bounds__(256) void upd_p_kernel(const UpdArgs* __restrict__ 
 }
 static inline size_t upd_solve_lds(int k) { return sizeof(double) * ((size_t)k * (k + 1) / 2 + 8); }
 
+// ================================================================================================
+// Information form of the stacked update for streams whose stacked Jacobian touches FEW columns (nc <= INFO_NC: the
+// two-camera pruning update, msckf.py:712-786, stacks ~5 rows per live feature -- 1,500 rows at 300 features -- over
+// exactly 12 columns).  With isotropic noise s^2 I and H = [0 Hc] (columns `cols`):
+//      K r        = P[:,c] (A Pcc + s^2 I)^-1 b,          A = Hc^T Hc  (nc x nc),   b = Hc^T r
+//      (I - K H)P = P - P[:,c] (A Pcc + s^2 I)^-1 A P[c,:]
+// (push-through identity Hc^T (Hc Pcc Hc^T + s^2 I)^-1 = (A Pcc + s^2 I)^-1 Hc^T), which is what msckf.py:548-602 computes
+// by thin QR + solve, without ever forming a triangular factor of the 1,500-row matrix: A and b are sums over the rows,
+// the only factorisation is a pivoted elimination of an nc x nc matrix.  A is singular (the projected Jacobian is blind to
+// a rigid motion of the camera pair), which is why the Gram matrix is never inverted -- only M = A Pcc + s^2 I is, and its
+// eigenvalues are s^2 + eig(Pcc^1/2 A Pcc^1/2) >= s^2.  One 256-thread workgroup per stream, ~36 KB of LDS, instead of a
+// 1024-thread QR workgroup that owns a CU plus five back-end launches.
+// ================================================================================================
+constexpr int INFO_NC = 24, INFO_CH = 96, INFO_MAXROWS = 8192;
+__host__ __device__ inline bool upd_info_form(int m, int nc) { return nc <= INFO_NC && m > nc && m <= INFO_MAXROWS; }
+static inline size_t upd_info_lds(int nc, int n, int m)
+{
+    return sizeof(double) * ((size_t)nc * nc + nc + (size_t)nc * (n + 1) + (size_t)nc * (nc + n + 2) + (size_t)INFO_CH * (INFO_NC + 1)) + sizeof(int) * ((size_t)m + 2) + 64;
+}
+
+__global__ __launch_bounds__(256) void upd_info_kernel(const UpdArgs* __restrict__ arr)
+{
+    extern __shared__ double Li[];
+    const UpdArgs a = arr[blockIdx.x];
+    if (a.m <= 0 || a.mode != 1) return;
+    const int tid = threadIdx.x, n = a.n, nc = a.nc, nb = a.n_blk;
+    double* A = Li;                          // [nc][nc]
+    double* bv = A + nc * nc;                // [nc]
+    double* Pc = bv + nc;                    // [nc][n+1]   rows cols[q] of P (P is symmetric: also its columns), pitch n+1
+    double* G = Pc + (size_t)nc * (n + 1);   // [nc][W]     augmented [M | F | b], W = nc + n + 1 (+1 pad)
+    const int PW_ = n + 1, W = nc + n + 2;
+    __shared__ int piv_row;
+    // 1. A = Hc^T Hc (upper triangle, then mirrored), b = Hc^T r.  The stacked rows are staged through LDS in chunks of INFO_CH
+    //    rows x (nc + 1) values by all 256 threads (the next chunk's loads are in flight while this one is summed); a thread
+    //    per entry of A / b then accumulates over the chunk.  Row map: stacked row i -> row of the feature-block buffer.
+    int* srow = reinterpret_cast<int*>(G + (size_t)nc * W);          // [m]
+    double* chunk = reinterpret_cast<double*>(srow + ((a.m + 1) & ~1));   // [INFO_CH][nc + 1]
+    {
+        int* pre = reinterpret_cast<int*>(chunk);                      // block prefix (inclusive), lives in the chunk buffer until the map is built
+        // inclusive scan of the block lengths: each thread sums a contiguous run, thread 0 scans the 256 run totals
+        const int per = (nb + 255) / 256;
+        int run = 0;
+        for (int u = 0; u < per; ++u) { const int b = tid * per + u; if (b < nb) { run += a.blk_len[b]; pre[b] = run; } }
+        __shared__ int tot[256];
+        tot[tid] = run;
+        __syncthreads();
+        if (tid == 0) { int acc = 0; for (int t = 0; t < 256; ++t) { const int v = tot[t]; tot[t] = acc; acc += v; } }
+        __syncthreads();
+        for (int u = 0; u < per; ++u) { const int b = tid * per + u; if (b < nb) pre[b] += tot[tid]; }
+        __syncthreads();
+        for (int b = tid; b < nb; b += 256) {
+            const int len = a.blk_len[b], r0 = a.blk_row[b], d0 = pre[b] - len;
+            for (int r = 0; r < len; ++r) srow[d0 + r] = r0 + r;
+        }
+        __syncthreads();
+    }
+    {
+        const int m = a.m, cw = nc + 1;
+        // entries: the nc (nc + 1) / 2 pairs (r, c <= r) of A, then the nc entries of b -- at most 324 for nc = 24: two per thread
+        const int ntri = nc * (nc + 1) / 2, nent = ntri + nc;
+        int ei[2], ej[2]; bool act[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int e = tid + 256 * v;
+            act[v] = e < nent;
+            if (e < ntri) {
+                int r = (int)((sqrtf(8.f * e + 1.f) - 1.f) * 0.5f);
+                while ((r + 1) * (r + 2) / 2 <= e) ++r;
+                while (r * (r + 1) / 2 > e) --r;
+                ei[v] = r; ej[v] = e - r * (r + 1) / 2;
+            } else { ei[v] = min(e - ntri, nc - 1); ej[v] = nc; }           // b: column nc of the staged rows is the residual
+        }
+        double acc[2] = {0, 0};
+        constexpr int PER = (INFO_CH * (INFO_NC + 1) + 255) / 256;
+        double stage[PER];
+        auto fetch = [&](int base) {
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int idx = tid + 256 * u, rr = idx / cw, cc = idx - rr * cw;
+                stage[u] = 0.0;
+                if (rr < INFO_CH && base + rr < m) { const int sr = srow[base + rr]; stage[u] = cc < nc ? a.Hsrc[(size_t)sr * a.ld + a.cols[cc]] : a.rsrc[sr]; }
+            }
+        };
+        fetch(0);
+        for (int base = 0; base < m; base += INFO_CH) {
+#pragma unroll
+            for (int u = 0; u < PER; ++u) { const int idx = tid + 256 * u; if (idx < INFO_CH * cw) chunk[idx] = stage[u]; }
+            __syncthreads();
+            if (base + INFO_CH < m) fetch(base + INFO_CH);            // next chunk's loads overlap this chunk's sums
+            const int rows = min(INFO_CH, m - base);
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+                if (act[v]) for (int rr = 0; rr < rows; ++rr) acc[v] = __builtin_fma(chunk[rr * cw + ei[v]], chunk[rr * cw + ej[v]], acc[v]);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+            if (act[v]) { if (ej[v] == nc) bv[ei[v]] = acc[v]; else { A[ei[v] * nc + ej[v]] = acc[v]; A[ej[v] * nc + ei[v]] = acc[v]; } }
+    }
+    for (int e = tid; e < nc * n; e += 256) { const int q = e / n, c = e - q * n; Pc[q * PW_ + c] = a.P[(size_t)a.cols[q] * a.ld + c]; }
+    __syncthreads();
+    // 2. F = A Pc (nc x n);  G = [F[:, cols] + s^2 I | F | b]
+    for (int e = tid; e < nc * n; e += 256) {
+        const int i = e / n, c = e - i * n;
+        double acc = 0;
+        for (int q = 0; q < nc; ++q) acc = __builtin_fma(A[i * nc + q], Pc[q * PW_ + c], acc);
+        G[i * W + nc + c] = acc;
+    }
+    for (int i = tid; i < nc; i += 256) G[i * W + nc + n] = bv[i];
+    __syncthreads();
+    for (int e = tid; e < nc * nc; e += 256) { const int i = e / nc, j = e - i * nc; G[i * W + j] = G[i * W + nc + a.cols[j]] + (i == j ? a.obs_noise : 0.0); }
+    __syncthreads();
+    // 3. Gauss-Jordan with partial pivoting on the augmented rows: afterwards G[:, nc:] = M^-1 [F | b] (scaled by the pivots)
+    for (int p = 0; p < nc; ++p) {
+        if (tid == 0) {
+            int best = p; double bm = fabs(G[p * W + p]);
+            for (int r = p + 1; r < nc; ++r) { const double v = fabs(G[r * W + p]); if (v > bm) { bm = v; best = r; } }
+            piv_row = best;
+        }
+        __syncthreads();
+        const int pr = piv_row;
+        if (pr != p) for (int c = tid; c < W - 1; c += 256) { const double t = G[p * W + c]; G[p * W + c] = G[pr * W + c]; G[pr * W + c] = t; }
+        __syncthreads();
+        const double inv = 1.0 / G[p * W + p];
+        // eliminate column p from every other row (columns > p only: the rest of column p is never read again)
+        for (int e = tid; e < nc * (W - 1 - (p + 1)); e += 256) {
+            const int r = e / (W - 1 - (p + 1)), c = p + 1 + (e - r * (W - 1 - (p + 1)));
+            if (r != p) G[r * W + c] = __builtin_fma(-G[r * W + p] * inv, G[p * W + c], G[r * W + c]);
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < nc * (n + 1); e += 256) { const int i = e / (n + 1), c = e - i * (n + 1); G[i * W + nc + c] /= G[i * W + i]; }
+    __syncthreads();
+    // 4. dx = P[:,c] X_b;   P <- sym(P - P[:,c] X): a thread per pair (r, c <= r), in place
+    const double* X = G + nc;                // X[q][c] = G[q*W + nc + c], c < n; X_b = column n
+    for (int c = tid; c < n; c += 256) {
+        double acc = 0;
+        for (int q = 0; q < nc; ++q) acc = __builtin_fma(Pc[q * PW_ + c], X[q * W + n], acc);
+        a.dx[c] = acc;
+    }
+    for (int e = tid; e < n * (n + 1) / 2; e += 256) {
+        int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        while (r * (r + 1) / 2 > e) --r;
+        const int c = e - r * (r + 1) / 2;
+        double trc = 0, tcr = 0;
+        for (int q = 0; q < nc; ++q) {
+            trc = __builtin_fma(Pc[q * PW_ + r], X[q * W + c], trc);
+            tcr = __builtin_fma(Pc[q * PW_ + c], X[q * W + r], tcr);
+        }
+        const double v = ((a.P[(size_t)r * a.ld + c] - trc) + (a.P[(size_t)c * a.ld + r] - tcr)) / 2.;
+        a.P[(size_t)r * a.ld + c] = v;
+        a.P[(size_t)c * a.ld + r] = v;
+    }
+}
+
 __global__ __launch_bounds__(UT) void update_front_kernel(UpdArgs a) { update_front(a); }
 __global__ __launch_bounds__(UT) void update_back_kernel(UpdArgs a) { update_back(a); }
 // `list` (optional): the streams to run, so that the 1024-thread workgroups exist only for the streams that really compress
@@ -1772,7 +1929,7 @@ __global__ __launch_bounds__(UT) void update_front_batch_kernel(const UpdArgs* _
 __global__ __launch_bounds__(256) void upd_gather_kernel(const UpdArgs* __restrict__ arr)
 {
     const UpdArgs a = arr[blockIdx.x];
-    if (a.m <= 0 || upd_compress(a.m, a.nc)) return;
+    if (a.m <= 0 || a.mode != 0 || upd_compress(a.m, a.nc)) return;
     __shared__ int srow[256], bstart[256];
     const int tid = threadIdx.x, m = a.m, nc = a.nc, nb = a.n_blk;        // m <= 144, every block has at least one row
     if (tid == 0) { int run = 0; for (int b = 0; b < nb; ++b) { bstart[b] = run; run += a.blk_len[b]; } }
@@ -1804,8 +1961,8 @@ static int msckf_lds_opt_in()
         const int lim = 160 * 1024;
         const void* fns[5] = {reinterpret_cast<const void*>(feature_kernel<16>), reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
                               reinterpret_cast<const void*>(update_front_kernel), reinterpret_cast<const void*>(update_front_batch_kernel)};
-        const void* fns2[3] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel),
-                               reinterpret_cast<const void*>(upd_chol_kernel)};
+        const void* fns2[4] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel),
+                               reinterpret_cast<const void*>(upd_chol_kernel), reinterpret_cast<const void*>(upd_info_kernel)};
         for (const void* f : fns2) {
             hipFuncAttributes at;
             hipError_t e = hipFuncGetAttributes(&at, f);
