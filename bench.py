@@ -34,15 +34,17 @@ W_IMG, H_IMG = 752, 480
 LK_BYTES_PER_POINT_PASS = 4 * 2 * 289 + 25          # L=4 levels x (I + J window of 17x17) + point I/O
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/s spec
 # rocprofv3 PMC passes of `bench.py --frontend-only --streams 64` (profiles/r02/pmc_frontend_s64_summary.json, collected by
-# profiles/r02/collect_pmc.sh: SQ block, FETCH_SIZE and WRITE_SIZE in three separate passes), per lk_track_g16_kernel launch
-# of 64 streams = 19,200 point passes:
-#   FETCH_SIZE 65,090.9 KB, WRITE_SIZE 264.3 KB (memory side of L2), SQ_INSTS_VALU 36,257,290 wave-instructions.
+# profiles/r02/collect_pmc.sh: SQ block, FETCH_SIZE and WRITE_SIZE in three separate passes), mean per lk_track_g16_kernel
+# launch over the launch mix of a step (temporal, stereo forward / backward of the tracked points: 300 point passes per stream
+# each; candidates round 1 forward / backward: 100 each; round 2: ~11 each), 64 streams per launch:
+#   FETCH_SIZE 37,629.7 KB, WRITE_SIZE 168.8 KB (memory side of L2), SQ_INSTS_VALU 21,364,230 wave-instructions.
+# bench.py's avg_launch_ms is the mean over the same mix, so per-launch means scale by streams / 64.
 # Traffic is corrected as MI355X_MICROARCH.md "HBM" prescribes for gfx950 (FETCH_SIZE x 2; WRITE_SIZE exact).  The x2 rule is
-# calibrated for 16-B/lane streams; this kernel stages its tiles with 4-byte lane loads, and the RAW figure (65 MB) is already
-# the size of the two pyramids a launch touches (64 streams x 2 x 560 KB = 72 MB): read the corrected value as an upper bound.
+# calibrated for 16-B/lane streams; this kernel stages its tiles with 4-byte lane loads, and the RAW figure is already about
+# the bytes of the pyramid regions a launch touches: read the corrected value as an upper bound.
 LK_PMC_STREAMS = 64
-LK_TRAFFIC_BYTES_PER_LAUNCH_S64 = (2 * 65090.9 + 264.3) * 1024
-LK_VALU_INSTS_PER_LAUNCH_S64 = 36257290.0
+LK_TRAFFIC_BYTES_PER_LAUNCH_S64 = (2 * 37629.7 + 168.8) * 1024
+LK_VALU_INSTS_PER_LAUNCH_S64 = 21364229.5
 VALU_CYCLES_PER_WAVE_INST = 2.0                     # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
 
@@ -546,7 +548,7 @@ def main():
                 'valu_issue_frac': ((LK_VALU_INSTS_PER_LAUNCH_S64 * S / LK_PMC_STREAMS) * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * CLOCK_HZ) / (lk_avg_ms * 1e-3)) if lk_avg_ms > 0 else None,
                 'valu_issue_frac_frontend_only': ((LK_VALU_INSTS_PER_LAUNCH_S64 * S / LK_PMC_STREAMS) * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * CLOCK_HZ) /
                                                   (timing_fe['lk'][0] / max(timing_fe['lk'][1], 1) * 1e-3)) if timing_fe else None,
-                'note': 'lk_track_g16_kernel is VALU-issue bound (PMC: 36.3 M VALU wave-instructions per launch of 19,200 point passes, 38% of wave '
+                'note': 'lk_track_g16_kernel is VALU-issue bound (PMC at 64 streams: 21.4 M VALU wave-instructions per launch on the mean over a step\'s launch mix, 38% of wave '
                         'cycles waiting on an instruction, LDS 2% of instructions); its tiles come from L2/Infinity Cache. The HBM fraction is '
                         'reported because the path class is byte/integer work; valu_issue_frac (2 cycles per wave64 instruction, 1,024 SIMDs at '
                         '2.4 GHz) is the bound that binds. In the complete path the span also contains the higher-priority filter kernels '
