@@ -880,7 +880,9 @@ struct UpdArgs {
     double obs_noise;
     int m;                                       // total stacked rows
     double* Sbuf;                                // batched back end: S = H P H^T + s^2 I, [k][ld] (lower triangle used)
-    int mode;                                    // batched back end: 0 = QR / Cholesky pipeline, 1 = information form (upd_info_kernel)
+    int mode;                                    // batched back end: 0 = Cholesky pipeline, 1 = information form (upd_info_kernel)
+    int kdir;                                    // batched back end: > 0 = rows kept (no QR compression: the stacked rows come in chunks), 0 = upd_k(m, nc)
+    int round;                                   // batched back end: chunk number of a sequential update (> 0: residual minus H dx so far, dx accumulates)
 };
 
 constexpr int UT = 1024;
@@ -1532,7 +1534,7 @@ __global__ __launch_bounds__(256) void upd_tt_kernel(const UpdArgs* __restrict__
 {
     const UpdArgs a = arr[blockIdx.y];
     if (a.m <= 0 || a.mode != 0) return;
-    const int k = upd_k(a.m, a.nc), n = a.n;
+    const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc)), n = a.n;
     const int r0 = (blockIdx.x / tiles_k) * GT, c0 = (blockIdx.x % tiles_k) * GT;      // rows: state index, columns: stacked row
     if (r0 >= n || c0 >= k) return;
     const size_t ldt = a.ldt;
@@ -1554,7 +1556,7 @@ __global__ __launch_bounds__(256) void upd_s_kernel(const UpdArgs* __restrict__ 
 {
     const UpdArgs a = arr[blockIdx.y];
     if (a.m <= 0 || a.mode != 0) return;
-    const int k = upd_k(a.m, a.nc);
+    const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
     int tr = (int)((sqrtf(8.f * blockIdx.x + 1.f) - 1.f) * 0.5f);              // triangular tile index -> (tr, tc), tc <= tr
     while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
     while (tr * (tr + 1) / 2 > (int)blockIdx.x) --tr;
@@ -1590,7 +1592,7 @@ __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict
     const UpdArgs a = arr[blockIdx.x];
     if (a.m <= 0 || a.mode != 0) return;
     const int tid = threadIdx.x;
-    const int k = upd_k(a.m, a.nc);
+    const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
     auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
     for (int e = tid; e < k * k; e += 256) {
         const int r = e / k, c = e - r * k;
@@ -1670,7 +1672,7 @@ __global__ __launch_bounds__(64) void upd_fsolve_kernel(const UpdArgs* __restric
 {
     const UpdArgs a = arr[blockIdx.y];
     if (a.m <= 0 || a.mode != 0) return;
-    const int n = a.n, nc = a.nc, k = upd_k(a.m, nc);
+    const int n = a.n, nc = a.nc, k = (a.kdir > 0 ? a.kdir : upd_k(a.m, nc));
     if ((int)blockIdx.x * 64 > n) return;
     const int c = blockIdx.x * 64 + threadIdx.x;
     const bool act = c <= n;
@@ -1712,7 +1714,7 @@ __global__ __launch_bounds__(256) void upd_p_kernel(const UpdArgs* __restrict__ 
 {
     const UpdArgs a = arr[blockIdx.y];
     if (a.m <= 0 || a.mode != 0) return;
-    const int n = a.n, k = upd_k(a.m, a.nc);
+    const int n = a.n, k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
     int tr = (int)((sqrtf(8.f * blockIdx.x + 1.f) - 1.f) * 0.5f);
     while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
     while (tr * (tr + 1) / 2 > (int)blockIdx.x) --tr;
@@ -1729,7 +1731,7 @@ __global__ __launch_bounds__(256) void upd_p_kernel(const UpdArgs* __restrict__ 
             double sacc = 0;
 #pragma unroll 8
             for (int i = 0; i < k; ++i) sacc += a.Kt[(size_t)i * a.ld + c] * rcol[i];
-            a.dx[c] = sacc;
+            a.dx[c] = a.round > 0 ? a.dx[c] + sacc : sacc;
         }
     }
     const int R0 = r0 + 4 * (threadIdx.x >> 4), C0 = c0 + 4 * (threadIdx.x & 15);
@@ -1929,7 +1931,7 @@ __global__ __launch_bounds__(UT) void update_front_batch_kernel(const UpdArgs* _
 __global__ __launch_bounds__(256) void upd_gather_kernel(const UpdArgs* __restrict__ arr)
 {
     const UpdArgs a = arr[blockIdx.x];
-    if (a.m <= 0 || a.mode != 0 || upd_compress(a.m, a.nc)) return;
+    if (a.m <= 0 || a.mode != 0 || (a.kdir <= 0 && upd_compress(a.m, a.nc))) return;
     __shared__ int srow[256], bstart[256];
     const int tid = threadIdx.x, m = a.m, nc = a.nc, nb = a.n_blk;        // m <= 144, every block has at least one row
     if (tid == 0) { int run = 0; for (int b = 0; b < nb; ++b) { bstart[b] = run; run += a.blk_len[b]; } }
@@ -1942,7 +1944,13 @@ __global__ __launch_bounds__(256) void upd_gather_kernel(const UpdArgs* __restri
         a.W[(size_t)q * ldt + row] = a.Hsrc[(size_t)srow[row] * a.ld + a.cols[q]];
     }
     double* rcol = a.W + (size_t)nc * ldt;
-    for (int row = tid; row < m; row += 256) rcol[row] = a.rsrc[srow[row]];
+    // later chunks of a sequential update see the state correction of the earlier ones: r' = r - H dx (the batch update of
+    // [H0; H1] equals the update with H0 followed by the update with H1 on (P1, r1 - H1 dx1); dx is injected once, at the end)
+    for (int row = tid; row < m; row += 256) {
+        double r = a.rsrc[srow[row]];
+        if (a.round > 0) for (int q = 0; q < nc; ++q) r = __builtin_fma(-a.Hsrc[(size_t)srow[row] * a.ld + a.cols[q]], a.dx[a.cols[q]], r);
+        rcol[row] = r;
+    }
 }
 __global__ __launch_bounds__(UT) void update_back_batch_kernel(const UpdArgs* __restrict__ arr)
 {
