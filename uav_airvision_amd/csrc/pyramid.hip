@@ -275,6 +275,104 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrArgs a, int level)
     *reinterpret_cast<uint32_t*>(dst + (size_t)yp * pitch + xq * 4) = out;
 }
 
+// Levels 2 AND 3 of one image by one workgroup: level 2 is filtered from the padded level 1 (global) into LDS, level 3 from
+// that LDS copy, and both 16-pixel frames are mirrored out of LDS.  The per-level gather kernel spends most of its time in the
+// frame at these sizes (52 % of the padded level 3 is frame, every frame pixel re-filters 25 source bytes through the
+// reflection); here a frame pixel is one LDS byte read.
+constexpr int L23_T = 1024;
+__global__ __launch_bounds__(L23_T) void pyr_l2l3_kernel(PyrArgs a)
+{
+    extern __shared__ uint8_t lds23[];
+    const int w1 = a.g.w[1], p1 = a.g.pitch[1];
+    const int w2 = a.g.w[2], h2 = a.g.h[2], p2 = a.g.pitch[2];
+    const int w3 = a.g.w[3], h3 = a.g.h[3], p3 = a.g.pitch[3];
+    const int lp2 = (w2 + 3) & ~3, lp3 = (w3 + 3) & ~3;             // LDS pitches (bytes)
+    uint8_t* l2 = lds23;                                            // [h2][lp2]
+    uint8_t* l3 = lds23 + (((size_t)h2 * lp2 + 15) & ~(size_t)15);  // [h3][lp3]
+    const int tid = threadIdx.x;
+    uint8_t* base = pyr_of(a, blockIdx.x);
+    const uint8_t* s1 = base + a.g.off[1] + (size_t)AV_PYR_BORDER * p1 + AV_PYR_BORDER;      // level-1 pixel (0,0); its frame is valid around it
+    uint8_t* d2 = base + a.g.off[2];
+    uint8_t* d3 = base + a.g.off[3];
+    (void)w1;
+    // ---- level 2 interior: quads of 4 pixels from five 16-byte source segments (as pyr_down_kernel) ----
+    const int q2 = lp2 >> 2;
+    for (int i = tid; i < q2 * h2; i += L23_T) {
+        const int y = i / q2, x0 = (i - y * q2) * 4;
+        const uint8_t* r0 = s1 + (ptrdiff_t)(2 * y - 2) * p1;
+        int hs[4][5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const uint4 d = *reinterpret_cast<const uint4*>(r0 + (size_t)k * p1 + 2 * x0 - 4);
+            const uint32_t t0 = __builtin_amdgcn_alignbyte(d.y, d.x, 2), t1 = d.y, t2 = __builtin_amdgcn_alignbyte(d.z, d.y, 2), t3 = d.z;
+            const uint32_t W4 = 0x04060401u;
+            hs[0][k] = (int)__builtin_amdgcn_udot4(t0, W4, (d.y >> 16) & 0xFF, false);
+            hs[1][k] = (int)__builtin_amdgcn_udot4(t1, W4, d.z & 0xFF, false);
+            hs[2][k] = (int)__builtin_amdgcn_udot4(t2, W4, (d.z >> 16) & 0xFF, false);
+            hs[3][k] = (int)__builtin_amdgcn_udot4(t3, W4, d.w & 0xFF, false);
+        }
+        uint32_t out = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int v = hs[c][0] + hs[c][4] + 4 * (hs[c][1] + hs[c][3]) + 6 * hs[c][2];
+            out |= (uint32_t)((v + 128) >> 8) << (8 * c);
+        }
+        *reinterpret_cast<uint32_t*>(l2 + y * lp2 + x0) = out;       // columns >= w2 of the last quad are never read back
+    }
+    __syncthreads();
+    // ---- padded level 2 out of LDS (interior and frame alike: a destination quad gathers 4 bytes through the reflection) ----
+    const int ph2 = h2 + 2 * AV_PYR_BORDER, pq2 = p2 >> 2;
+    for (int i = tid; i < pq2 * ph2; i += L23_T) {
+        const int yp = i / pq2, xq = i - yp * pq2;
+        const int y = av_reflect101(yp - AV_PYR_BORDER, h2);
+        uint32_t out = 0;
+        const int xs = xq * 4 - AV_PYR_BORDER;
+        if (xs >= 0 && xs + 4 <= w2) out = *reinterpret_cast<const uint32_t*>(l2 + y * lp2 + xs);
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { int x = av_reflect101(xs + c, w2); x = min(max(x, 0), w2 - 1); out |= (uint32_t)l2[y * lp2 + x] << (8 * c); }
+        }
+        *reinterpret_cast<uint32_t*>(d2 + (size_t)yp * p2 + xq * 4) = out;
+    }
+    // ---- level 3 interior from the LDS copy of level 2 (reflect-101 at its border) ----
+    const int q3 = lp3 >> 2;
+    for (int i = tid; i < q3 * h3; i += L23_T) {
+        const int y = i / q3, x0 = (i - y * q3) * 4;
+        uint32_t out = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int x = x0 + c;
+            int v = 0;
+            if (x < w3) {
+                int hsum[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const uint8_t* r = l2 + av_reflect101(2 * y - 2 + k, h2) * lp2;
+                    const int xm2 = av_reflect101(2 * x - 2, w2), xm1 = av_reflect101(2 * x - 1, w2), xp1 = av_reflect101(2 * x + 1, w2), xp2 = av_reflect101(2 * x + 2, w2);
+                    hsum[k] = (int)r[xm2] + (int)r[xp2] + 4 * ((int)r[xm1] + (int)r[xp1]) + 6 * (int)r[2 * x];
+                }
+                v = (hsum[0] + hsum[4] + 4 * (hsum[1] + hsum[3]) + 6 * hsum[2] + 128) >> 8;
+            }
+            out |= (uint32_t)v << (8 * c);
+        }
+        *reinterpret_cast<uint32_t*>(l3 + y * lp3 + x0) = out;
+    }
+    __syncthreads();
+    const int ph3 = h3 + 2 * AV_PYR_BORDER, pq3 = p3 >> 2;
+    for (int i = tid; i < pq3 * ph3; i += L23_T) {
+        const int yp = i / pq3, xq = i - yp * pq3;
+        const int y = av_reflect101(yp - AV_PYR_BORDER, h3);
+        uint32_t out = 0;
+        const int xs = xq * 4 - AV_PYR_BORDER;
+        if (xs >= 0 && xs + 4 <= w3) out = *reinterpret_cast<const uint32_t*>(l3 + y * lp3 + xs);
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { int x = av_reflect101(xs + c, w3); x = min(max(x, 0), w3 - 1); out |= (uint32_t)l3[y * lp3 + x] << (8 * c); }
+        }
+        *reinterpret_cast<uint32_t*>(d3 + (size_t)yp * p3 + xq * 4) = out;
+    }
+}
+
 }  // namespace
 
 PyrGeom av_make_geom(const av_pyr_layout& l)
@@ -314,7 +412,22 @@ int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stri
         hipLaunchKernelGGL(pad_level0_kernel, grid, dim3(256), 0, st, a);
         AV_LAUNCH_CHECK();
     }
-    for (int l = fused ? 2 : 1; l < g.levels; ++l) {
+    // levels 2 + 3 by one workgroup per image when the level-2 image fits in LDS
+    const size_t lds23 = g.levels == 4 ? ((((size_t)g.h[2] * ((g.w[2] + 3) & ~3) + 15) & ~(size_t)15) + (size_t)g.h[3] * ((g.w[3] + 3) & ~3) + 16) : 0;
+    const bool fused23 = g.levels == 4 && lds23 <= 60 * 1024 && (g.pitch[1] & 3) == 0 && !getenv("AV_PYR_UNFUSED");
+    int lbeg = fused ? 2 : 1;
+    if (fused23) {
+        if (!fused) {
+            int quads = (g.pitch[1] >> 2) * (g.h[1] + 2 * AV_PYR_BORDER);
+            dim3 grid((quads + 255) / 256, n_img);
+            hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, st, a, 1);
+            AV_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(pyr_l2l3_kernel, dim3(n_img), dim3(L23_T), lds23, st, a);
+        AV_LAUNCH_CHECK();
+        lbeg = g.levels;
+    }
+    for (int l = lbeg; l < g.levels; ++l) {
         int quads = (g.pitch[l] >> 2) * (g.h[l] + 2 * AV_PYR_BORDER);
         dim3 grid((quads + 255) / 256, n_img);
         hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, st, a, l);
