@@ -537,6 +537,89 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
     constexpr int GX = TEAM == 256 ? 16 : (TEAM == 64 ? 8 : 4), GY = TEAM / GX;
     const int tx = tid % GX, ty = tid / GX;
     double g = 0;
+    if (TEAM == 256 && K > 16) {
+        // Workgroup teams (long tracks, K up to 77): BLOCKED Cholesky of the bordered matrix [[S, r'], [r'^T, .]] -- the border
+        // row comes out as y = L^-1 r' and gamma = y^T y.  Panels of 8 columns: the 8 x 8 diagonal block by one thread in
+        // registers, the panel (and the border row) one row per thread, the trailing block by a 16 x 16 thread grid: three
+        // barriers per eight columns where the column-by-column form below pays one per column, and at these sizes the
+        // barrier is most of a step (60 us of a 150 us block at 17 observations).
+        constexpr int NB = 8;
+        for (int j0 = 0; j0 < K; j0 += NB) {
+            const int nb = min(NB, K - j0), jb = j0 + nb;
+            if (tid == 0) {
+                double A[NB][NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) A[i][j] = (i < nb) ? Sg[(j0 + i) * SP + j0 + j] : (i == j ? 1.0 : 0.0);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    double d = A[j][j];
+#pragma unroll
+                    for (int t = 0; t < j; ++t) d -= A[j][t] * A[j][t];
+                    d = sqrt(d);
+                    A[j][j] = d;
+                    const double inv = 1.0 / d;
+#pragma unroll
+                    for (int i = j + 1; i < NB; ++i) {
+                        double v = A[i][j];
+#pragma unroll
+                        for (int t = 0; t < j; ++t) v -= A[i][t] * A[j][t];
+                        A[i][j] = v * inv;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) if (i < nb) Sg[(j0 + i) * SP + j0 + j] = A[i][j];
+            }
+            __syncthreads();
+            {   // panel rows jb..K-1 and the border row (index K): x <- x L11^-T
+                const int i = jb + tid;
+                if (i <= K) {
+                    double* xr = i < K ? Sg + i * SP + j0 : wv + j0;
+                    double x[NB];
+#pragma unroll
+                    for (int t = 0; t < NB; ++t) x[t] = t < nb ? xr[t] : 0.0;
+#pragma unroll
+                    for (int t = 0; t < NB; ++t) if (t < nb) {
+                        double v = x[t];
+#pragma unroll
+                        for (int u = 0; u < t; ++u) v -= x[u] * Sg[(j0 + t) * SP + j0 + u];
+                        x[t] = v / Sg[(j0 + t) * SP + j0 + t];
+                    }
+#pragma unroll
+                    for (int t = 0; t < NB; ++t) if (t < nb) xr[t] = x[t];
+                }
+            }
+            __syncthreads();
+            if (jb < K) {
+                for (int i = jb + ty; i <= K; i += GY) {          // trailing block, border row included (i == K)
+                    const double* li = i < K ? Sg + i * SP + j0 : wv + j0;
+                    double lr[NB];
+#pragma unroll
+                    for (int t = 0; t < NB; ++t) lr[t] = t < nb ? li[t] : 0.0;
+                    if (i < K) {
+                        for (int c = jb + tx; c <= i; c += GX) {
+                            double v = Sg[i * SP + c];
+#pragma unroll
+                            for (int t = 0; t < NB; ++t) if (t < nb) v -= lr[t] * Sg[c * SP + j0 + t];
+                            Sg[i * SP + c] = v;
+                        }
+                    } else {
+                        for (int c = jb + tx; c < K; c += GX) {
+                            double v = wv[c];
+#pragma unroll
+                            for (int t = 0; t < NB; ++t) if (t < nb) v -= lr[t] * Sg[c * SP + j0 + t];
+                            wv[c] = v;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (tid == 0) { for (int k = 0; k < K; ++k) g += wv[k] * wv[k]; }
+    } else
     for (int k = 0; k < K; ++k) {
         const double inv = 1.0 / Sg[k * SP + k];
         const double wk = wv[k], zk = wk * inv;
