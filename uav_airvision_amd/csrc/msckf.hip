@@ -296,6 +296,11 @@ struct FeatArgs {
     unsigned long long* prof;            // optional [8] phase stamps of team 0 (diagnostic runs, AV_MSCKF_TIMING)
     int zero_fill;                       // 1: clear the full-width output rows first (columns of cameras the feature was not seen
                                          // from must read as zero); 0: the caller gathers only this feature's own camera columns
+    // chained launches (batched filter): a feature triangulated by the triangulate_kernel launch just ahead on the same HIP
+    // stream takes its position straight from that kernel's output (no host round trip between the two); a feature whose
+    // triangulation failed is not evaluated and reads pass = 0 (msckf.py:646-656, 749-757: it is dropped before the Jacobian)
+    const int* tri_idx;                  // [n_feat] index into tri_pos / tri_valid, or -1 = position known (`pos`); NULL = none
+    const double* tri_pos; const int* tri_valid;
 };
 
 // dynamic LDS of feature_kernel for tracks of at most Mx observations (layout at the top of the kernel)
@@ -335,6 +340,11 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
     const int o0 = a.obs_off[f], M = a.obs_off[f + 1] - o0;
     const int R4 = 4 * M, C6 = 6 * M, K = R4 - 3;
     const int Mx = a.Mmax;
+    const int tri = a.tri_idx ? a.tri_idx[f] : -1;
+    if (tri == -2 || (tri >= 0 && !a.tri_valid[tri])) {   // -2: failed check_motion on the host                  // whole team (uniform in f): triangulation failed, nothing to gate
+        if (tid == 0) { a.gamma[f] = 0.0; a.pass[f] = 0; }
+        return;
+    }
     double* H = sm;                              // [4Mx][6Mx]  row-major, stride C6
     double* Hf = H + (4 * Mx) * (6 * Mx);        // [4Mx][3]
     double* rr = Hf + (4 * Mx) * 3;              // [4Mx]
@@ -361,7 +371,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
         double t1[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) t1[r] = t0[r] - (Rw1[0 * 3 + r] * a.t01[0] + Rw1[1 * 3 + r] * a.t01[1] + Rw1[2 * 3 + r] * a.t01[2]);
-        const double* pw = a.pos + 3 * f;
+        const double* pw = tri >= 0 ? a.tri_pos + 3 * tri : a.pos + 3 * f;
         double d0[3] = {pw[0] - t0[0], pw[1] - t0[1], pw[2] - t0[2]}, d1[3] = {pw[0] - t1[0], pw[1] - t1[1], pw[2] - t1[2]};
         double p0[3], p1[3];
 #pragma unroll
@@ -2035,6 +2045,105 @@ __global__ __launch_bounds__(256) void upd_gather_kernel(const UpdArgs* __restri
         rcol[row] = r;
     }
 }
+// ================================================================================================
+// Stacking decisions of remove_lost_features / prune_cam_state_buffer ON THE DEVICE (msckf.py:658-668, 759-763): which gated
+// blocks are stacked (in feature = map order, up to the `> 1500 rows` cut), which camera columns they touch, and how the
+// stacked rows are split into the sequential chunks of the batched back end.  One wavefront per stream.  The host only
+// knows upper bounds (it launches `rounds` rounds of back-end kernels; rounds a stream does not need see m = 0 and exit),
+// so the gate flags never travel to the host between the feature kernels and the update.
+// ================================================================================================
+constexpr int STACK_LDS_BLOCKS = 4096;          // = 4 * UT, the block-list limit of the back end
+struct StackArgs {
+    const int* rbeg;                 // [S + 1] feature range of every stream (features are stream-major, map order inside)
+    const int* pass;                 // [n_feat] gate flags of feature_kernel
+    const int* obs_off; const int* obs_cam;      // the feature kernels' observation CSR (camera slot per observation)
+    const int* row_off;              // [n_feat] first row of every feature's block
+    int* blk_row; int* blk_len;      // out: stacked blocks of stream s at [rbeg[s], rbeg[s] + n_blk)
+    int* cols; int cols_stride;      // out: touched state columns of stream s at cols + s * cols_stride (ascending)
+    const UpdArgs* base;             // [S] per-stream constants (pointers, n, ld, ...); base.mode = 1: information form allowed
+    UpdArgs* out;                    // [rounds][S]
+    int S, rounds, cut1500, kch;
+    int* stacked;                    // out [S]: rows stacked (0 = no update), -1 = more chunks than `rounds` (nothing is updated)
+};
+__global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
+{
+    __shared__ int s_len[STACK_LDS_BLOCKS];
+    __shared__ int s_chunk[64];                          // first block of chunk c (c < rounds <= 63), then the end
+    __shared__ int s_nch;
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int i0 = a.rbeg[s], i1 = a.rbeg[s + 1];
+    int stacked = 0, nb = 0;
+    unsigned long long used = 0ull;
+    bool overflow = false;
+    for (int base = i0; base < i1; base += 64) {
+        const int i = base + lane;
+        const bool in = i < i1;
+        const int o0 = in ? a.obs_off[i] : 0, nobs = in ? a.obs_off[i + 1] - o0 : 0;
+        const int rows = 4 * nobs - 3;
+        const int v = (in && a.pass[i]) ? rows : 0;
+        int incl = v;                                    // inclusive prefix sum over the wavefront
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        const int before = stacked + incl - v;           // rows stacked when the reference reaches this feature
+        const bool take = v > 0 && (!a.cut1500 || before <= 1500);       // the loop breaks once stacked > 1500 (msckf.py:667-668)
+        const unsigned long long mask = __ballot(take);
+        const int pos = nb + __popcll(mask & ((1ull << lane) - 1ull));
+        if (take) {
+            if (pos < STACK_LDS_BLOCKS) s_len[pos] = rows; else overflow = true;
+            a.blk_row[i0 + pos] = a.row_off[i]; a.blk_len[i0 + pos] = rows;
+            for (int q = 0; q < nobs; ++q) used |= 1ull << a.obs_cam[o0 + q];
+        }
+        nb += __popcll(mask);
+        int add = take ? v : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) add += __shfl_xor(add, d, 64);
+        stacked += add;
+        if (a.cut1500 && stacked > 1500) break;          // uniform
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { used |= __shfl_xor(used, d, 64); }
+    overflow = __ballot(overflow) != 0ull;
+    const UpdArgs b = a.base[s];
+    const int nc = 6 * __popcll(used);
+    const int m = overflow ? 0 : stacked;
+    const int mode = (m > 0 && b.mode == 1 && upd_info_form(m, nc)) ? 1 : 0;
+    __syncthreads();
+    if (lane == 0) {
+        int c = 0;
+        for (int ci = 0; ci < 64; ++ci) if (used >> ci & 1ull) for (int e = 0; e < 6; ++e) a.cols[(size_t)s * a.cols_stride + c++] = IMU_DIM + 6 * ci + e;
+        int nch = 0;
+        if (m > 0 && mode == 0) {                        // next-fit chunks of at most kch rows (a block is never split)
+            int acc = 0;
+            s_chunk[nch++] = 0;
+            for (int k = 0; k < nb; ++k) {
+                const int len = s_len[k];
+                if (acc + len > a.kch) { if (nch < 63) s_chunk[nch] = k; ++nch; acc = 0; }
+                acc += len;
+            }
+            if (nch <= 62) s_chunk[nch] = nb;
+        }
+        s_nch = nch;
+    }
+    __syncthreads();
+    const int nch = s_nch;
+    const bool too_many = nch > a.rounds || nch > 62;
+    if (lane == 0) a.stacked[s] = overflow || too_many ? -1 : m;
+    for (int r = lane; r < a.rounds; r += 64) {
+        UpdArgs u = b;
+        u.mode = mode; u.round = r; u.kdir = 0; u.nc = nc; u.cols = a.cols + (size_t)s * a.cols_stride;
+        u.blk_row = a.blk_row + i0; u.blk_len = a.blk_len + i0; u.n_blk = nb; u.m = (too_many || overflow) ? 0 : m;
+        if (u.m > 0 && mode == 0) {
+            if (r < nch) {
+                const int b0 = s_chunk[r], b1 = s_chunk[r + 1];
+                int rows = 0;
+                for (int k = b0; k < b1; ++k) rows += s_len[k];
+                u.blk_row += b0; u.blk_len += b0; u.n_blk = b1 - b0; u.m = rows; u.kdir = rows;
+            } else u.m = 0;
+        } else if (r > 0) u.m = 0;                       // information form: one launch, round 0 only
+        a.out[(size_t)r * a.S + s] = u;
+    }
+}
+
 __global__ __launch_bounds__(UT) void update_back_batch_kernel(const UpdArgs* __restrict__ arr)
 {
     const UpdArgs a = arr[blockIdx.x];
@@ -2249,7 +2358,7 @@ AV_EXPORT int av_msckf_feature_blocks(av_msckf* c, int n_feat, int n_cam, int ma
     for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) a.R01[r * 3 + cc] = T_cam0_cam1_rowmajor44[r * 4 + cc]; a.t01[r] = T_cam0_cam1_rowmajor44[r * 4 + 3]; a.gravity[r] = gravity[r]; }
     a.obs_noise = obs_noise; a.Hout = c->Hblk; a.rout = c->rblk; a.gamma = gamma_dev; a.pass = pass_dev; a.Mmax = max_obs;
     a.feat_stream = nullptr; a.stream_ncam = nullptr; a.stream_gravity = nullptr; a.cam_stride = 0; a.p_stride = a.h_stride = a.r_stride = 0;
-    a.feat_list = nullptr; a.prof = nullptr; a.zero_fill = 1;
+    a.feat_list = nullptr; a.prof = nullptr; a.zero_fill = 1; a.tri_idx = nullptr; a.tri_pos = nullptr; a.tri_valid = nullptr;
     AV_HIP(hipSetDevice(c->device));
     return launch_feature_kernel(a, n_feat, max_obs, (hipStream_t)stream);
 }
