@@ -33,6 +33,14 @@ namespace {
 
 constexpr int IMU_DIM = 21;
 
+// The batched filter's kernels are short and on the step's critical path, and they share their CUs with the front-end's
+// long-running throughput waves (other HIP streams): VALU issue is arbitrated by wave priority first, age second
+// (MI355X_MICROARCH.md, "Two waves per SIMD" item 2), so these kernels raise their waves' priority once at entry.
+#ifndef AV_FILTER_WAVE_PRIO
+#define AV_FILTER_WAVE_PRIO 3
+#endif
+#define AV_FILTER_PRIO() __builtin_amdgcn_s_setprio(AV_FILTER_WAVE_PRIO)
+
 __device__ __forceinline__ void quat_to_rot(const double* qin, double* R)
 {
     // utils.py:12-23: normalise, R = (2w^2-1) I - 2w [v]x + 2 v v^T
@@ -125,6 +133,7 @@ __device__ __forceinline__ void solve3(const double A[9], const double b[3], dou
 
 __global__ __launch_bounds__(256) void triangulate_kernel(TriArgs a)
 {
+    AV_FILTER_PRIO();
     const int lane = threadIdx.x & 63;
     const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (f >= a.n_feat) return;
@@ -325,6 +334,7 @@ __device__ __forceinline__ void team_sync()
 template <int TEAM>
 __device__ __forceinline__ void feature_body(const FeatArgs& a)
 {
+    AV_FILTER_PRIO();
     extern __shared__ double sm_all[];
     const int slot = TEAM == 256 ? (int)blockIdx.x : (int)(blockIdx.x * (256 / TEAM) + threadIdx.x / TEAM);
     if (slot >= a.n_list) return;                         // whole team
@@ -841,6 +851,7 @@ __global__ __launch_bounds__(256) void propagate_kernel(PropArgs a) { propagate_
 // batched: block b applies samples first[b] .. first[b+1]-1 in order (one stream per block)
 __global__ __launch_bounds__(256) void propagate_batch_kernel(const PropArgs* arr, const int* first)
 {
+    AV_FILTER_PRIO();
     __shared__ double P11s[IMU_DIM * IMU_DIM], PhiT[IMU_DIM * IMU_DIM];
     const int i0 = first[blockIdx.x], i1 = first[blockIdx.x + 1];
     if (i0 >= i1) return;                                   // block-uniform
@@ -923,7 +934,7 @@ __device__ __forceinline__ void augment_body(const AugArgs& a)
 }
 
 __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) { augment_body(a); }
-__global__ __launch_bounds__(256) void augment_batch_kernel(const AugArgs* arr) { augment_body(arr[blockIdx.x]); }
+__global__ __launch_bounds__(256) void augment_batch_kernel(const AugArgs* arr) { AV_FILTER_PRIO(); augment_body(arr[blockIdx.x]); }
 
 // ================================================================================================
 // Delete the 6 rows/cols of one camera state (msckf.py:774-786)
@@ -949,6 +960,7 @@ __global__ __launch_bounds__(256) void remove_cam_kernel(double* P, double* scra
 // batched: two removals per stream, the second index already refers to the matrix after the first removal
 __global__ __launch_bounds__(256) void remove_cam_batch_kernel(const RemArgs* arr)
 {
+    AV_FILTER_PRIO();
     const RemArgs a = arr[blockIdx.x];
     if (a.start0 < 0) return;
     remove_cam_body(a.P, a.scratch, a.n, a.ld, a.start0);
@@ -1625,6 +1637,7 @@ __device__ __forceinline__ void gemm_tile64(int Q, int r0, int c0, FA loadA, FB 
 // T^T[c][r] = sum_q P[cols[q]][c] * Wt[q][r]   (c < n, r < k), stored [n][ld] in a.T
 __global__ __launch_bounds__(256) void upd_tt_kernel(const UpdArgs* __restrict__ arr, int tiles_k)
 {
+    AV_FILTER_PRIO();
     const UpdArgs a = arr[blockIdx.y];
     if (a.m <= 0 || a.mode != 0) return;
     const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc)), n = a.n;
@@ -1647,6 +1660,7 @@ __global__ __launch_bounds__(256) void upd_tt_kernel(const UpdArgs* __restrict__
 // S[r][c] = sum_q T^T[cols[q]][r] * Wt[q][c] + s^2 [r == c]   (r, c < k; tiles on and below the diagonal)
 __global__ __launch_bounds__(256) void upd_s_kernel(const UpdArgs* __restrict__ arr)
 {
+    AV_FILTER_PRIO();
     const UpdArgs a = arr[blockIdx.y];
     if (a.m <= 0 || a.mode != 0) return;
     const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
@@ -1681,6 +1695,7 @@ __global__ __launch_bounds__(256) void upd_s_kernel(const UpdArgs* __restrict__ 
 constexpr int CNB = 8;
 __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict__ arr)
 {
+    AV_FILTER_PRIO();
     extern __shared__ double Lp[];
     const UpdArgs a = arr[blockIdx.x];
     if (a.m <= 0 || a.mode != 0) return;
@@ -1751,9 +1766,11 @@ __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict
         }
         __syncthreads();
     }
+    // L is written as a symmetric matrix: the substitution kernel reads eight consecutive rows of one COLUMN of L per step,
+    // which the mirrored upper triangle holds contiguously (one 64-byte scalar load instead of eight)
     for (int e = tid; e < k * k; e += 256) {
         const int r = e / k, c = e - r * k;
-        if (c <= r) a.Sbuf[(size_t)r * a.ld + c] = at(r, c);
+        a.Sbuf[(size_t)r * a.ld + c] = c <= r ? at(r, c) : at(c, r);
     }
 }
 
@@ -1763,6 +1780,7 @@ __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict
 // load per L entry -- and the workgroups of one stream spread over three CUs instead of idling 114 threads of one.
 __global__ __launch_bounds__(64) void upd_fsolve_kernel(const UpdArgs* __restrict__ arr)
 {
+    AV_FILTER_PRIO();
     const UpdArgs a = arr[blockIdx.y];
     if (a.m <= 0 || a.mode != 0) return;
     const int n = a.n, nc = a.nc, k = (a.kdir > 0 ? a.kdir : upd_k(a.m, nc));
@@ -1783,11 +1801,14 @@ __global__ __launch_bounds__(64) void upd_fsolve_kernel(const UpdArgs* __restric
         int row[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) row[u] = min(i0 + u, k - 1) * ld;
+        // rows i0 .. i0+7 of column q: L^T(q, i0 + u) = Sbuf[q * ld + i0 + u] (i0 and ld are multiples of 8: one 64-byte line;
+        // the entries past row k - 1 of the last block multiply into accumulators that are never stored)
 #pragma unroll 4
         for (int q = 0; q < i0; ++q) {
             const double yq = act ? y[(size_t)q * st_] : 0.0;
+            scalar_ptr Lq = L + q * ld + i0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] = __builtin_fma(-L[row[u] + q], yq, acc[u]);
+            for (int u = 0; u < 8; ++u) acc[u] = __builtin_fma(-Lq[u], yq, acc[u]);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -1805,6 +1826,7 @@ __global__ __launch_bounds__(64) void upd_fsolve_kernel(const UpdArgs* __restric
 // reads its sub-tile of P and the mirror sub-tile, then writes both -- every unordered pair {(r,c), (c,r)} has one owner.
 __global__ __launch_bounds__(256) void upd_p_kernel(const UpdArgs* __restrict__ arr)
 {
+    AV_FILTER_PRIO();
     const UpdArgs a = arr[blockIdx.y];
     if (a.m <= 0 || a.mode != 0) return;
     const int n = a.n, k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
@@ -1877,6 +1899,7 @@ static inline size_t upd_info_lds(int nc, int n, int m)
 
 __global__ __launch_bounds__(256) void upd_info_kernel(const UpdArgs* __restrict__ arr)
 {
+    AV_FILTER_PRIO();
     extern __shared__ double Li[];
     const UpdArgs a = arr[blockIdx.x];
     if (a.m <= 0 || a.mode != 1) return;
@@ -2023,6 +2046,7 @@ __global__ __launch_bounds__(UT) void update_front_batch_kernel(const UpdArgs* _
 // gathered into the transposed work matrix: a 256-thread workgroup, no QR machinery.
 __global__ __launch_bounds__(256) void upd_gather_kernel(const UpdArgs* __restrict__ arr)
 {
+    AV_FILTER_PRIO();
     const UpdArgs a = arr[blockIdx.x];
     if (a.m <= 0 || a.mode != 0 || (a.kdir <= 0 && upd_compress(a.m, a.nc))) return;
     __shared__ int srow[256], bstart[256];
@@ -2067,6 +2091,7 @@ struct StackArgs {
 };
 __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
 {
+    AV_FILTER_PRIO();
     __shared__ int s_len[STACK_LDS_BLOCKS];
     __shared__ int s_chunk[64];                          // first block of chunk c (c < rounds <= 63), then the end
     __shared__ int s_nch;
