@@ -107,8 +107,9 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
                  const LKParams& p, hipStream_t st, const int* index = nullptr);
 
 // fast.hip
+void av_fast_tiles(int w, int h, int* tiles, int* tile_cap);         // tile count of a w x h image, entries per tile list
 int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, int border, const uint8_t* mask, int64_t mask_stride,
                    int n_img, int w, int h, int threshold,
                    uint32_t* kp, int* count, int cap,                               // flat output (ops API) or NULL
-                   uint32_t* cell_kp, int* cell_count, int cell_cap, int gh, int gw, int grid_col, int n_cells,   // per-cell output or NULL
-                   int* n_fast, int* overflow, int stat_stride, hipStream_t st);
+                   uint32_t* tile_kp, int* tile_count,                              // per-tile output (front-end engine) or NULL
+                   int* overflow, int stat_stride, hipStream_t st);

@@ -18,8 +18,10 @@
 //  (2) the ~200-op corner score for the compacted candidates only (dense lanes instead of a divergent early-out);
 //  (3) 3x3 non-max suppression, again a dword of four scores per lane with its eight neighbouring dwords; quads with no
 //      positive score (most) leave after one read.
-// Survivors go to an LDS list first, then ONE returning global atomic per (tile, grid cell) reserves their slots in the
-// per-cell candidate lists of the feature adder (or in a flat list).
+// Survivors go to an LDS list first.  The front-end engine takes them as PER-TILE lists (tile_kp / tile_count: plain
+// coalesced stores, every tile writes its count, no atomics and nothing to wait for -- the returning global atomics of a
+// per-cell list were a quarter of the kernel's time); its select kernel bins them into grid cells.  The stand-alone
+// detector (av_fast_detect) appends them to one flat list per image with one returning atomic per tile.
 // Bound: HBM read of the image (w*h bytes) -- the score arithmetic is ~200 VALU ops per candidate.
 #include <stdlib.h>
 
@@ -32,7 +34,7 @@ constexpr int PW = TW + 8, PH = TH + 8;     // pixel tile: columns x0-4 .. x0+67
 constexpr int PWD = PW / 4;                 // 18 dwords per pixel row
 constexpr int SP = PW, SH = TH + 2;         // score tile: column index = pc (same dword phase as the pixels), row sr = y - y0 + 1
 constexpr int SPD = SP / 4;
-constexpr int MAXLC = 16;                   // grid cells one tile may overlap
+constexpr int TCAP = TW * TH / 4;           // strict 3x3 maxima in one tile: at most one per 2x2 block
 
 struct FastArgs {
     const uint8_t* img;
@@ -43,8 +45,8 @@ struct FastArgs {
     int64_t mask_stride;
     int w, h, threshold;
     uint32_t* kp; int* count; int cap;
-    uint32_t* cell_kp; int* cell_count; int cell_cap, gh, gw, grid_col, n_cells;
-    int* n_fast; int* overflow; int stat_stride;
+    uint32_t* tile_kp; int* tile_count;          // [n_img][tiles][TCAP], [n_img][tiles] (tiles row-major: blockIdx.y * gridDim.x + blockIdx.x)
+    int* overflow; int stat_stride;
     int dbg;
 };
 
@@ -188,16 +190,10 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
     // Phase 3: 3x3 non-max suppression + mask; survivors go to an LDS list first so that the tile issues
     // ONE returning global atomic per output list it touches (a 64x16 tile overlaps <= 4 grid cells)
     // instead of one per keypoint.
-    __shared__ uint32_t surv_word[TW * TH / 4];             // strict 3x3 maxima: at most one per 2x2 block
-    __shared__ int surv_cell[TW * TH / 4];
-    __shared__ int nsurv, cell_base[MAXLC], cell_cnt[MAXLC], flat_base;
+    __shared__ uint32_t surv_word[TCAP];
+    __shared__ int nsurv, flat_base;
     if (tid == 0) nsurv = 0;
-    if (tid < MAXLC) cell_cnt[tid] = 0;
     __syncthreads();
-    // grid cells overlapped by this tile: columns cx0..cx0+ncx-1, rows cy0..cy0+ncy-1 (ncx*ncy <= MAXLC)
-    const int cx0 = a.cell_kp ? x0 / a.gw : 0, cy0 = a.cell_kp ? y0 / a.gh : 0;
-    const int ncx = a.cell_kp ? (min(x0 + TW - 1, a.w - 1) / a.gw - cx0 + 1) : 1;
-    const int ncy = a.cell_kp ? (min(y0 + TH - 1, a.h - 1) / a.gh - cy0 + 1) : 1;
     // quads of the tile interior: columns pc = 4q .. 4q+3, q = 1..16 (x = x0 .. x0+63), score rows sr = 1..48 (y = y0 .. y0+47)
 #pragma unroll
     for (int it = 0; it < (TW / 4) * TH / 256; ++it) {
@@ -226,71 +222,54 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
                 keep = keep && s > (int)(tri & 0xFF) && s > (int)((tri >> 16) & 0xFF) && (d == 1 || s > (int)((tri >> 8) & 0xFF));
             }
             if (keep && a.mask) keep = mask_dw ? ((mask4[it] >> (8 * k)) & 0xFF) != 0 : a.mask[img_i * a.mask_stride + (size_t)y * a.w + x] != 0;
-            if (keep) {
-                const int slot = atomicAdd(&nsurv, 1);            // LDS atomic; a tile has <= TW*TH/4 strict maxima
-                const int lc = a.cell_kp ? ((y / a.gh - cy0) * ncx + (x / a.gw - cx0)) : 0;      // tile-local cell index
+            if (keep && !(a.dbg & 8)) {
+                const int slot = atomicAdd(&nsurv, 1);            // LDS atomic; a tile has <= TCAP strict maxima
                 surv_word[slot] = ((uint32_t)s << AV_KP_RASTER_BITS) | (AV_KP_RASTER_MASK - (uint32_t)(y * a.w + x));
-                surv_cell[slot] = lc | (atomicAdd(&cell_cnt[lc], 1) << 8);          // rank inside its cell (lists are unordered: any rank will do)
             }
         }
     }
     __syncthreads();
     const int ns = nsurv;
-    if (ns == 0) return;
-    if (tid < ncx * ncy) {
-        const int cnt = cell_cnt[tid];
-        int base = 0;
-        if (a.cell_kp && cnt > 0) {
-            const int cell = (cy0 + tid / ncx) * a.grid_col + (cx0 + tid % ncx);
-            base = atomicAdd(&a.cell_count[img_i * a.n_cells + cell], cnt);
-        }
-        cell_base[tid] = base;
-        if (tid == 0) {
-            if (a.n_fast) atomicAdd(&a.n_fast[img_i * a.stat_stride], ns);
-            flat_base = a.kp ? atomicAdd(&a.count[img_i], ns) : 0;
-        }
+    if (a.tile_kp) {
+        const size_t tile = (size_t)img_i * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x;
+        if (tid == 0) a.tile_count[tile] = ns;
+        for (int q = tid; q < ns; q += 256) a.tile_kp[tile * TCAP + q] = surv_word[q];
+        return;
     }
+    if (ns == 0) return;
+    if (tid == 0) flat_base = atomicAdd(&a.count[img_i], ns);
     __syncthreads();
     for (int q = tid; q < ns; q += 256) {
-        const uint32_t word = surv_word[q];
-        if (a.kp) {
-            const int idx = flat_base + q;
-            if (idx < a.cap) a.kp[(size_t)img_i * a.cap + idx] = word;
-            else if (a.overflow) atomicOr(&a.overflow[img_i * a.stat_stride], 1);
-        }
-        if (a.cell_kp) {
-            const int lc = surv_cell[q] & 0xFF, rank = surv_cell[q] >> 8;
-            const int cell = (cy0 + lc / ncx) * a.grid_col + (cx0 + lc % ncx);
-            const int idx = cell_base[lc] + rank;
-            if (idx < a.cell_cap) a.cell_kp[((size_t)img_i * a.n_cells + cell) * a.cell_cap + idx] = word;
-            else if (a.overflow) atomicOr(&a.overflow[img_i * a.stat_stride], 2);
-        }
+        const int idx = flat_base + q;
+        if (idx < a.cap) a.kp[(size_t)img_i * a.cap + idx] = surv_word[q];
+        else if (a.overflow) atomicOr(&a.overflow[img_i * a.stat_stride], 1);
     }
 }
 
 }  // namespace
 
+void av_fast_tiles(int w, int h, int* tiles, int* tile_cap)
+{
+    *tiles = ((w + TW - 1) / TW) * ((h + TH - 1) / TH);
+    *tile_cap = TCAP;
+}
+
+// Exactly one of (kp, count, cap) -- a flat list per image -- and (tile_kp, tile_count) -- per-tile lists, see av_fast_tiles -- is given.
 int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, int border, const uint8_t* mask, int64_t mask_stride,
                    int n_img, int w, int h, int threshold,
-                   uint32_t* kp, int* count, int cap,
-                   uint32_t* cell_kp, int* cell_count, int cell_cap, int gh, int gw, int grid_col, int n_cells,
-                   int* n_fast, int* overflow, int stat_stride, hipStream_t st)
+                   uint32_t* kp, int* count, int cap, uint32_t* tile_kp, int* tile_count,
+                   int* overflow, int stat_stride, hipStream_t st)
 {
     if (n_img <= 0) return AV_OK;
     if ((int64_t)w * h > (int64_t)(AV_KP_RASTER_MASK + 1)) {
         av_set_error("av_fast_detect: image %dx%d exceeds 2^19 pixels", w, h);
         return AV_E_INVALID;
     }
-    if (cell_kp && ((TW + gw - 1) / gw + 1) * ((TH + gh - 1) / gh + 1) > MAXLC) {
-        av_set_error("FAST: grid cells of %dx%d pixels are too small (a %dx%d tile may overlap at most %d cells)", gw, gh, TW, TH, MAXLC);
-        return AV_E_INVALID;
-    }
     FastArgs a;
     a.img = img; a.img_stride = img_stride; a.img_pitch = img_pitch; a.border = border; a.mask = mask; a.mask_stride = mask_stride;
     a.w = w; a.h = h; a.threshold = threshold;
     a.kp = kp; a.count = count; a.cap = cap;
-    a.cell_kp = cell_kp; a.cell_count = cell_count; a.cell_cap = cell_cap; a.gh = gh; a.gw = gw;
-    a.grid_col = grid_col; a.n_cells = n_cells; a.n_fast = n_fast; a.overflow = overflow; a.stat_stride = stat_stride;
+    a.tile_kp = tile_kp; a.tile_count = tile_count; a.overflow = overflow; a.stat_stride = stat_stride;
     { const char* e = getenv("AV_FAST_DBG"); a.dbg = e ? atoi(e) : 0; }
     dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, n_img);
     hipLaunchKernelGGL(fast_kernel, grid, dim3(256), 0, st, a);
@@ -309,5 +288,5 @@ AV_EXPORT int av_fast_detect(const uint8_t* img_dev, int64_t img_stride, const u
     hipStream_t st = (hipStream_t)stream;
     AV_HIP(hipMemsetAsync(count_dev, 0, sizeof(int) * (size_t)n_img, st));
     return av_launch_fast(img_dev, img_stride, w, 0, mask_dev, mask_stride, n_img, w, h, threshold, kp_dev, count_dev, cap,
-                          nullptr, nullptr, 0, 1, 1, 1, 1, nullptr, nullptr, 0, st);
+                          nullptr, nullptr, nullptr, 0, st);
 }

@@ -60,6 +60,7 @@ struct FeDev {
     long long* cur_id; int* cur_life; float* cur_p0; float* cur_p1; int* cur_cell; int* cur_count;
     // FAST per-cell lists + mask
     uint32_t* cell_kp; int* cell_count; uint8_t* mask;
+    uint32_t* tile_kp; int* tile_count; int n_tiles, tile_cap;      // FAST survivors per detector tile (fast.hip), binned into cells by select_kernel
     // candidates for new features
     uint32_t* cand_key; float* cand_p0; float* cand_init; float* cand_p1; uint8_t* cand_st; float* cand_back; uint8_t* cand_st2;
     uint8_t* cand_inl; int* cand_off; int* cand_count;
@@ -237,10 +238,37 @@ __global__ __launch_bounds__(256) void select_kernel(FeDev d)
     extern __shared__ int sm[];
     int* cnt = sm;               // [C]
     int* off = sm + d.C;         // [C+1]
+    int* ccnt = off + d.C + 1;   // [C]   FAST keypoints per cell
+    int* tpre = ccnt + d.C;      // [n_tiles + 1] prefix of the detector's per-tile counts
     const int s = blockIdx.x;
     const bool first = d.first_frame[s] != 0;
+    // bin the detector's per-tile survivor lists into the per-cell lists (feature_adder.py:66-71: row = y / grid_height,
+    // col = x / grid_width).  The cell lists are unordered; everything below orders by (response, raster) key.
+    {
+        const int nt = d.n_tiles;
+        for (int c = threadIdx.x; c < d.C; c += 256) ccnt[c] = 0;
+        for (int t = threadIdx.x; t < nt; t += 256) tpre[t + 1] = d.tile_count[(size_t)s * nt + t];
+        __syncthreads();
+        if (threadIdx.x == 0) { tpre[0] = 0; for (int t = 0; t < nt; ++t) tpre[t + 1] += tpre[t]; }
+        __syncthreads();
+        const int E = tpre[nt];
+        for (int i = threadIdx.x; i < E; i += 256) {
+            int lo = 0, hi = nt;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tpre[mid] <= i) lo = mid; else hi = mid; }
+            const uint32_t word = d.tile_kp[((size_t)s * nt + lo) * d.tile_cap + (i - tpre[lo])];
+            const uint32_t raster = AV_KP_RASTER_MASK - (word & AV_KP_RASTER_MASK);
+            const int y = (int)(raster / (uint32_t)d.w), x = (int)(raster % (uint32_t)d.w);
+            const int cell = (y / d.gh) * d.grid_col + x / d.gw;
+            const int idx = atomicAdd(&ccnt[cell], 1);
+            if (idx < d.cell_cap) d.cell_kp[((size_t)s * d.C + cell) * d.cell_cap + idx] = word;
+            else atomicOr(&d.counters[s * NCNT + CNT_OVF], 2);
+        }
+        if (threadIdx.x == 0) d.counters[s * NCNT + CNT_FAST] = E;
+        __threadfence_block();
+        __syncthreads();
+    }
     for (int c = threadIdx.x; c < d.C; c += 256) {
-        int n = min(d.cell_count[s * d.C + c], d.cell_cap);
+        int n = min(ccnt[c], d.cell_cap);
         cnt[c] = first ? n : min(n, d.gmax);
     }
     __syncthreads();
@@ -276,7 +304,7 @@ __global__ __launch_bounds__(256) void select_kernel(FeDev d)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int c = wv; c < d.C; c += 4) {
         const uint32_t* list = d.cell_kp + ((size_t)s * d.C + c) * d.cell_cap;
-        const int n = min(d.cell_count[s * d.C + c], d.cell_cap);
+        const int n = min(ccnt[c], d.cell_cap);
         const int take = cnt[c];
         uint32_t* dst = d.cand_key + (size_t)s * d.CC + off[c];
         if (first) {
@@ -695,11 +723,10 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
     // tile but the right-most column copies whole dwords without clamping)
     const uint8_t* fast_img = P_cur0 + fe->geom.off[0] + (size_t)AV_PYR_BORDER * fe->geom.pitch[0] + AV_PYR_BORDER;
     if ((rc = av_launch_fast(fast_img, sstride, fe->geom.pitch[0], AV_PYR_BORDER, d.mask, (int64_t)d.w * d.h, S, d.w, d.h, fe->cfg.fast_threshold,
-                             nullptr, nullptr, 0, d.cell_kp, d.cell_count, d.cell_cap, d.gh, d.gw, d.grid_col, d.C,
-                             d.counters + CNT_FAST, d.counters + CNT_OVF, NCNT, st))) { delete fast_span; return rc; }
+                             nullptr, nullptr, 0, d.tile_kp, d.tile_count, d.counters + CNT_OVF, NCNT, st))) { delete fast_span; return rc; }
     delete fast_span;
     { Span sp(fe, 3, st);
-      hipLaunchKernelGGL(select_kernel, dim3(S), dim3(256), sizeof(int) * (2 * d.C + 1), st, d);
+      hipLaunchKernelGGL(select_kernel, dim3(S), dim3(256), sizeof(int) * (3 * d.C + 1 + d.n_tiles + 1), st, d);
       AV_LAUNCH_CHECK(); }
     const int r1_launch = any_first ? d.CC : d.C * (d.gmax < CAND_R1 ? d.gmax : CAND_R1);
     { Span sp(fe, 1, st);
@@ -787,6 +814,8 @@ AV_EXPORT int av_frontend_create(const av_frontend_config* cfg, int n_streams, i
     A(d.sv_back, 2 * S * d.NT) A(d.sv_st2, S * d.NT)
     A(d.cur_id, S * d.NT) A(d.cur_life, S * d.NT) A(d.cur_p0, 2 * S * d.NT) A(d.cur_p1, 2 * S * d.NT) A(d.cur_cell, S * d.NT)
     A(d.cell_kp, (size_t)S * C * d.cell_cap)
+    av_fast_tiles(w, h, &d.n_tiles, &d.tile_cap);
+    A(d.tile_kp, (size_t)S * d.n_tiles * d.tile_cap) A(d.tile_count, (size_t)S * d.n_tiles)
     if ((rc = dev_alloc(fe, &d.mask, (size_t)S * w * h, 1))) { av_frontend_destroy(fe); return rc; }
     A(d.cand_key, (size_t)S * d.CC) A(d.cand_p0, 2 * (size_t)S * d.CC) A(d.cand_init, 2 * (size_t)S * d.CC) A(d.cand_p1, 2 * (size_t)S * d.CC)
     A(d.cand_st, (size_t)S * d.CC) A(d.cand_back, 2 * (size_t)S * d.CC) A(d.cand_st2, (size_t)S * d.CC) A(d.cand_inl, (size_t)S * d.CC)
