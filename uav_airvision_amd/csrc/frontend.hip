@@ -244,28 +244,49 @@ __global__ __launch_bounds__(256) void select_kernel(FeDev d)
     const bool first = d.first_frame[s] != 0;
     // bin the detector's per-tile survivor lists into the per-cell lists (feature_adder.py:66-71: row = y / grid_height,
     // col = x / grid_width).  The cell lists are unordered; everything below orders by (response, raster) key.
+    // Dense mapping, no search: slot j of a chunk is entry (j % BK) + kb of tile j / BK; a round issues BU independent loads
+    // per thread (list word, then its mask byte) -- this loop is a chain of memory round trips, not work.
     {
+        __shared__ int tmax;
         const int nt = d.n_tiles;
+        constexpr int BK = 32, BU = 5;
+        if (threadIdx.x == 0) tmax = 0;
         for (int c = threadIdx.x; c < d.C; c += 256) ccnt[c] = 0;
-        for (int t = threadIdx.x; t < nt; t += 256) tpre[t + 1] = d.tile_count[(size_t)s * nt + t];
         __syncthreads();
-        if (threadIdx.x == 0) { tpre[0] = 0; for (int t = 0; t < nt; ++t) tpre[t + 1] += tpre[t]; }
+        int mx = 0;
+        for (int t = threadIdx.x; t < nt; t += 256) { const int n = d.tile_count[(size_t)s * nt + t]; tpre[t] = n; mx = max(mx, n); }
+        if (mx > 0) atomicMax(&tmax, mx);
         __syncthreads();
-        const int E = tpre[nt];
-        for (int i = threadIdx.x; i < E; i += 256) {
-            int lo = 0, hi = nt;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tpre[mid] <= i) lo = mid; else hi = mid; }
-            const uint32_t word = d.tile_kp[((size_t)s * nt + lo) * d.tile_cap + (i - tpre[lo])];
-            const uint32_t raster = AV_KP_RASTER_MASK - (word & AV_KP_RASTER_MASK);
-            const int y = (int)(raster / (uint32_t)d.w), x = (int)(raster % (uint32_t)d.w);
-            const int cell = (y / d.gh) * d.grid_col + x / d.gw;
-            const int idx = atomicAdd(&ccnt[cell], 1);
-            if (idx < d.cell_cap) d.cell_kp[((size_t)s * d.C + cell) * d.cell_cap + idx] = word;
-            else atomicOr(&d.counters[s * NCNT + CNT_OVF], 2);
-        }
-        if (threadIdx.x == 0) d.counters[s * NCNT + CNT_FAST] = E;
+        const int maxcount = tmax;
+        for (int kb = 0; kb < maxcount; kb += BK)
+            for (int j0 = threadIdx.x; j0 < nt * BK; j0 += 256 * BU) {
+                uint32_t word[BU]; int x[BU], y[BU]; bool ok[BU]; uint8_t mk[BU];
+#pragma unroll
+                for (int u = 0; u < BU; ++u) {
+                    const int j = j0 + 256 * u, t = j / BK, k = kb + (j % BK);
+                    ok[u] = j < nt * BK && k < tpre[min(t, nt - 1)];
+                    word[u] = ok[u] ? d.tile_kp[((size_t)s * nt + t) * d.tile_cap + k] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < BU; ++u) {
+                    const uint32_t raster = AV_KP_RASTER_MASK - (word[u] & AV_KP_RASTER_MASK);
+                    y[u] = (int)(raster / (uint32_t)d.w); x[u] = (int)(raster % (uint32_t)d.w);
+                    // detect(img, mask) drops keypoints on masked pixels AFTER the non-max suppression (fast.hip header): the mask
+                    // byte is read here, for the few thousand survivors, instead of for every pixel inside the detector
+                    mk[u] = ok[u] ? d.mask[(size_t)s * d.w * d.h + (size_t)y[u] * d.w + x[u]] : (uint8_t)0;
+                }
+#pragma unroll
+                for (int u = 0; u < BU; ++u) {
+                    if (!ok[u] || mk[u] == 0) continue;
+                    const int cell = (y[u] / d.gh) * d.grid_col + x[u] / d.gw;
+                    const int idx = atomicAdd(&ccnt[cell], 1);
+                    if (idx < d.cell_cap) d.cell_kp[((size_t)s * d.C + cell) * d.cell_cap + idx] = word[u];
+                    else atomicOr(&d.counters[s * NCNT + CNT_OVF], 2);
+                }
+            }
         __threadfence_block();
         __syncthreads();
+        if (threadIdx.x == 0) { int tot = 0; for (int c = 0; c < d.C; ++c) tot += ccnt[c]; d.counters[s * NCNT + CNT_FAST] = tot; }
     }
     for (int c = threadIdx.x; c < d.C; c += 256) {
         int n = min(ccnt[c], d.cell_cap);
@@ -310,10 +331,18 @@ __global__ __launch_bounds__(256) void select_kernel(FeDev d)
         if (first) {
             for (int i = lane; i < take; i += 64) dst[i] = list[i];
         } else {
+            // the first 4 x 64 keys of the list live in registers for all `take` selection rounds (re-reading the list from HBM
+            // every round made this kernel a chain of ~75 memory round trips per wavefront); longer lists read the rest per round
+            constexpr int KR = 4;
+            uint32_t kreg[KR];
+#pragma unroll
+            for (int u = 0; u < KR; ++u) kreg[u] = lane + 64 * u < n ? list[lane + 64 * u] : 0u;
             uint32_t last = 0xFFFFFFFFu;
             for (int r = 0; r < take; ++r) {
                 uint32_t best = 0;
-                for (int i = lane; i < n; i += 64) { uint32_t k = list[i]; if (k < last && k > best) best = k; }
+#pragma unroll
+                for (int u = 0; u < KR; ++u) if (kreg[u] < last && kreg[u] > best) best = kreg[u];
+                for (int i = lane + 64 * KR; i < n; i += 64) { uint32_t k = list[i]; if (k < last && k > best) best = k; }
                 best = (uint32_t)wave_max_u64(best);
                 if (lane == 0) dst[r] = best;
                 last = best;
@@ -722,7 +751,7 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
     // FAST reads level 0 of the cam0 pyramid built above (same pixels as the input image, with a 16-pixel frame: every
     // tile but the right-most column copies whole dwords without clamping)
     const uint8_t* fast_img = P_cur0 + fe->geom.off[0] + (size_t)AV_PYR_BORDER * fe->geom.pitch[0] + AV_PYR_BORDER;
-    if ((rc = av_launch_fast(fast_img, sstride, fe->geom.pitch[0], AV_PYR_BORDER, d.mask, (int64_t)d.w * d.h, S, d.w, d.h, fe->cfg.fast_threshold,
+    if ((rc = av_launch_fast(fast_img, sstride, fe->geom.pitch[0], AV_PYR_BORDER, nullptr, 0, S, d.w, d.h, fe->cfg.fast_threshold,
                              nullptr, nullptr, 0, d.tile_kp, d.tile_count, d.counters + CNT_OVF, NCNT, st))) { delete fast_span; return rc; }
     delete fast_span;
     { Span sp(fe, 3, st);
