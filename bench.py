@@ -37,14 +37,14 @@ HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/
 # profiles/r02/collect_pmc.sh: SQ block, FETCH_SIZE and WRITE_SIZE in three separate passes), mean per lk_track_g16_kernel
 # launch over the launch mix of a step (temporal, stereo forward / backward of the tracked points: 300 point passes per stream
 # each; candidates round 1 forward / backward: 100 each; round 2: ~11 each), 64 streams per launch:
-#   FETCH_SIZE 37,629.7 KB, WRITE_SIZE 168.8 KB (memory side of L2), SQ_INSTS_VALU 21,364,230 wave-instructions.
+#   FETCH_SIZE 37,720.6 KB, WRITE_SIZE 169.0 KB (memory side of L2), SQ_INSTS_VALU 21,366,779 wave-instructions.
 # bench.py's avg_launch_ms is the mean over the same mix, so per-launch means scale by streams / 64.
 # Traffic is corrected as MI355X_MICROARCH.md "HBM" prescribes for gfx950 (FETCH_SIZE x 2; WRITE_SIZE exact).  The x2 rule is
 # calibrated for 16-B/lane streams; this kernel stages its tiles with 4-byte lane loads, and the RAW figure is already about
 # the bytes of the pyramid regions a launch touches: read the corrected value as an upper bound.
 LK_PMC_STREAMS = 64
-LK_TRAFFIC_BYTES_PER_LAUNCH_S64 = (2 * 37629.7 + 168.8) * 1024
-LK_VALU_INSTS_PER_LAUNCH_S64 = 21364229.5
+LK_TRAFFIC_BYTES_PER_LAUNCH_S64 = (2 * 37720.6 + 169.0) * 1024
+LK_VALU_INSTS_PER_LAUNCH_S64 = 21366779.0
 VALU_CYCLES_PER_WAVE_INST = 2.0                     # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
 
