@@ -316,7 +316,8 @@ struct FeatArgs {
 static inline size_t feature_lds_bytes(int Mx, int team = 256)
 {
     const size_t red = team == 256 ? 256 : 0;           // tree-reduction scratch of the workgroup teams only
-    return sizeof(double) * ((size_t)(4 * Mx) * (6 * Mx) + (4 * Mx) * 3 + 4 * Mx + (size_t)(4 * Mx) * (4 * Mx + 1) + red) + sizeof(int) * Mx + 16;
+    // Hb [4Mx][6] + alpha [3][6Mx] + Hf [4Mx][3] + r [4Mx] + S [4Mx][4Mx+1] (+ reduction scratch) + camera indices
+    return sizeof(double) * ((size_t)(4 * Mx) * 6 + 3 * (size_t)(6 * Mx) + (4 * Mx) * 3 + 4 * Mx + (size_t)(4 * Mx) * (4 * Mx + 1) + red) + sizeof(int) * Mx + 16;
 }
 
 // TEAM = threads that cooperate on one feature: a whole 256-thread workgroup for long tracks, one wavefront (four
@@ -355,15 +356,20 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
         if (tid == 0) { a.gamma[f] = 0.0; a.pass[f] = 0; }
         return;
     }
-    double* H = sm;                              // [4Mx][6Mx]  row-major, stride C6
-    double* Hf = H + (4 * Mx) * (6 * Mx);        // [4Mx][3]
+    // H_x is block diagonal (observation j: rows 4j..4j+3, its camera's 6 columns) and stays that way in LDS: only the blocks
+    // are stored.  The null-space projection Q^T H_x (three Householder reflectors from H_f) is never materialised either --
+    // column c of it is  H_x[:, c] - alpha0[c] u0 - alpha1[c] u1 - alpha2[c] u2  with three scalars per column (below), and
+    // its rows go straight to global memory.  (A dense [4M][6M] copy was 85 KB of the 147 KB this kernel held at 21
+    // observations, which kept whole CUs away from the front-end's kernels.)
+    double* Hb = sm;                             // [4Mx][6]   H_x blocks: row 4j+r, column c of camera block j
+    double* al = Hb + (4 * Mx) * 6;              // [3][6Mx]   reflector coefficients per column
+    double* Hf = al + 3 * (6 * Mx);              // [4Mx][3]
     double* rr = Hf + (4 * Mx) * 3;              // [4Mx]
     double* S = rr + 4 * Mx;                     // [4Mx][4Mx+1]  (odd row pitch: row-wise reflector jobs stay off the same banks)
     double* red = S + (4 * Mx) * (4 * Mx + 1);   // [256] reduction scratch
     const int SP = R4 + 1;
     int* cidx = reinterpret_cast<int*>(red + (TEAM == 256 ? 256 : 0));   // [Mx] camera index per observation
 
-    for (int i = tid; i < R4 * C6; i += TEAM) H[i] = 0.0;
     for (int i = tid; i < M; i += TEAM) cidx[i] = a.obs_cam[o0 + i];
     team_sync<TEAM>();
     if (a.prof && slot == 0 && tid == 0) a.prof[0] = __builtin_amdgcn_s_memrealtime();
@@ -434,7 +440,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
             for (int c = 0; c < 6; ++c) Au += A[r][c] * u[c];
             double hx[6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) { hx[c] = A[r][c] - Au * u[c] / uu; H[(4 * j + r) * C6 + 6 * j + c] = hx[c]; }
+            for (int c = 0; c < 6; ++c) { hx[c] = A[r][c] - Au * u[c] / uu; Hb[(4 * j + r) * 6 + c] = hx[c]; }
 #pragma unroll
             for (int c = 0; c < 3; ++c) Hf[(4 * j + r) * 3 + c] = -hx[3 + c];
             rr[4 * j + r] = zz[r] - zh[r];
@@ -450,8 +456,8 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
     for (int pr = tid; pr < M * M; pr += TEAM) {
         const int j = pr / M, l = pr - j * M;
         const double* Pb = Pm + (size_t)(IMU_DIM + 6 * cidx[j]) * a.ld + IMU_DIM + 6 * cidx[l];
-        const double* Hj = H + (4 * j) * C6 + 6 * j;
-        const double* Hl = H + (4 * l) * C6 + 6 * l;
+        const double* Hj = Hb + (4 * j) * 6;
+        const double* Hl = Hb + (4 * l) * 6;
         double t[4][6] = {{0}};
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -460,7 +466,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
             for (int d = 0; d < 6; ++d) pv[d] = Pb[(size_t)c * a.ld + d];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double h = Hj[r * C6 + c];
+                const double h = Hj[r * 6 + c];
 #pragma unroll
                 for (int d = 0; d < 6; ++d) t[r][d] += h * pv[d];
             }
@@ -469,7 +475,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
         for (int s2 = 0; s2 < 4; ++s2) {
             double hl[6];
 #pragma unroll
-            for (int d = 0; d < 6; ++d) hl[d] = Hl[s2 * C6 + d];
+            for (int d = 0; d < 6; ++d) hl[d] = Hl[s2 * 6 + d];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 double g = 0;
@@ -483,6 +489,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
 
     if (a.prof && slot == 0 && tid == 0) a.prof[2] = __builtin_amdgcn_s_memrealtime();
     // ---- left null space of H_f by 3 Householder reflectors, applied to H and r (msckf.py:540-544) --
+    double v0s[3], taus[3];                          // reflector k: u_k = (0.., v0s[k] at row k, Hf[k+1.., k]), H_k = I - taus[k] u_k u_k^T
     for (int k = 0; k < 3; ++k) {
         // norm of Hf[k:, k]
         double part = 0;
@@ -502,7 +509,8 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
         const double v0 = akk - alpha;                     // v = x - alpha e1, stored in place in Hf[k:, k] (v0 kept apart)
         const double vtv = nrm * nrm - 2 * alpha * akk + alpha * alpha;      // |v|^2
         const double tau = vtv > 0 ? 2.0 / vtv : 0.0;
-        // columns to transform: all C6 columns of H, the remaining Hf columns (k+1..2), r, and the R4 columns of G
+        v0s[k] = v0; taus[k] = tau;
+        // columns to transform: the remaining Hf columns (k+1..2), r, and the R4 columns of G (H_x: see below)
         auto reflect = [&](double* col, int stride) {
             double dot = v0 * col[k * stride];
 #pragma unroll 8
@@ -512,12 +520,11 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
 #pragma unroll 8
             for (int i = k + 1; i < R4; ++i) col[i * stride] -= dot * Hf[i * 3 + k];
         };
-        const int nfix = C6 + (2 - k) + 1, njobs = nfix + R4;
+        const int nfix = (2 - k) + 1, njobs = nfix + R4;
         for (int job = tid; job < njobs; job += TEAM) {
             // one call site: the lanes of a wavefront differ only in (column, stride), not in control flow
             double* col; int stride;
-            if (job < C6) { col = H + job; stride = C6; }
-            else if (job < C6 + (2 - k)) { col = Hf + (k + 1 + job - C6); stride = 3; }
+            if (job < 2 - k) { col = Hf + (k + 1 + job); stride = 3; }
             else if (job < nfix) { col = rr; stride = 1; }
             else { col = S + (job - nfix); stride = SP; }
             reflect(col, stride);
@@ -537,9 +544,34 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
             }
             team_sync<TEAM>();
         }
+        // Q^T H_x = H2 H1 H0 H_x column by column: with d_k = u_k^T col (four products: the column has four non-zeros),
+        //   alpha0 = tau0 d0,  alpha1 = tau1 (d1 - alpha0 u1.u0),  alpha2 = tau2 (d2 - alpha0 u2.u0 - alpha1 u2.u1)
+        // and rows >= 3 of u_k are Hf[., k] (the rows that are kept).
+        auto uk = [&](int k, int i) -> double { return i < k ? 0.0 : (i == k ? v0s[k] : Hf[i * 3 + k]); };
+        double g10 = 0, g20 = 0, g21 = 0;                     // u1.u0, u2.u0, u2.u1 (every thread: <= 3 x 84 LDS broadcasts)
+        for (int i = 1; i < R4; ++i) {
+            const double u0 = uk(0, i), u1 = uk(1, i), u2 = uk(2, i);
+            g10 += u1 * u0; g20 += u2 * u0; g21 += u2 * u1;
+        }
+        for (int c = tid; c < C6; c += TEAM) {
+            const int j = c / 6, cc = c - 6 * j;
+            double d0 = 0, d1 = 0, d2 = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double h = Hb[(4 * j + r) * 6 + cc];
+                d0 += uk(0, 4 * j + r) * h; d1 += uk(1, 4 * j + r) * h; d2 += uk(2, 4 * j + r) * h;
+            }
+            const double a0 = taus[0] * d0;
+            const double a1 = taus[1] * (d1 - a0 * g10);
+            const double a2 = taus[2] * (d2 - a0 * g20 - a1 * g21);
+            al[c] = a0; al[C6 + c] = a1; al[2 * C6 + c] = a2;
+        }
+        team_sync<TEAM>();
         for (int i = tid; i < K * C6; i += TEAM) {
-            const int rI = i / C6, c = i - rI * C6;
-            Hout[(size_t)(row0 + rI) * a.ld + IMU_DIM + 6 * cidx[c / 6] + c % 6] = H[(3 + rI) * C6 + c];
+            const int rI = i / C6, c = i - rI * C6, row = 3 + rI, j = c / 6;
+            double v = (row >> 2) == j ? Hb[row * 6 + (c - 6 * j)] : 0.0;
+            v -= al[c] * Hf[row * 3] + al[C6 + c] * Hf[row * 3 + 1] + al[2 * C6 + c] * Hf[row * 3 + 2];
+            Hout[(size_t)(row0 + rI) * a.ld + IMU_DIM + 6 * cidx[j] + (c - 6 * j)] = v;
         }
         for (int i = tid; i < K; i += TEAM) rout[row0 + i] = rr[3 + i];
     }
