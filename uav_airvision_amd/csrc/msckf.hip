@@ -2163,7 +2163,8 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
     const UpdArgs b = a.base[s];
     const int nc = 6 * __popcll(used);
     const int m = overflow ? 0 : stacked;
-    const int mode = (m > 0 && b.mode == 1 && upd_info_form(m, nc)) ? 1 : 0;
+    // (the information form holds for any m >= 1; a stream the host marked for it never needs a Cholesky round)
+    const int mode = (m > 0 && b.mode == 1 && nc <= INFO_NC && m <= INFO_MAXROWS) ? 1 : 0;
     __syncthreads();
     if (lane == 0) {
         int c = 0;
