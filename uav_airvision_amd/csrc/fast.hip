@@ -50,30 +50,46 @@ struct FastArgs {
     int dbg;
 };
 
+// Corner score of one candidate, the 16 ring differences two to a register (packed 16-bit lanes: ring position j in the low
+// half, its antipode j + 8 in the high half, j = 0..7).  The circular sliding minima / maxima of cornerScore<16>
+// (windows of 2, 4, then 9 = 4 + 4 + 1) become 8 packed operations per stage instead of 16: "the next position" of the pair
+// (j, j + 8) is the pair (j + 1, j + 9), and past the end of the array it is an earlier pair with its halves swapped, which
+// the packed instructions take for free through their operand half selects.
+typedef short av_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ av_s2 s2_swap(av_s2 x) { return __builtin_shufflevector(x, x, 1, 0); }
+__device__ __forceinline__ av_s2 s2_min(av_s2 a, av_s2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ av_s2 s2_max(av_s2 a, av_s2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ int fast_score(const uint8_t* c, int t)
 {
     // c points at the centre pixel inside the LDS pixel tile (row stride PW)
     constexpr int DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     constexpr int DY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
     const int v = c[0];
-    int d[16];
+    const av_s2 v2 = {(short)v, (short)v};
+    av_s2 D[8];                                     // d[j] = v - ring[j], d[j + 8]
 #pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] = v - (int)c[DY[k] * PW + DX[k]];
-    // sliding min / max over circular windows of 9
-    int lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { lo4[i] = min(lo2[i], lo2[(i + 2) & 15]); hi4[i] = max(hi2[i], hi2[(i + 2) & 15]); }
-    int A = -256, Bm = 256;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int lo9 = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
-        int hi9 = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
-        A = max(A, lo9);        // best arc of "centre brighter than ring by at least"
-        Bm = min(Bm, hi9);      // best arc of "centre darker than ring by at least" (negated)
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t pk = (uint32_t)c[DY[j] * PW + DX[j]] | ((uint32_t)c[DY[j + 8] * PW + DX[j + 8]] << 16);
+        D[j] = v2 - __builtin_bit_cast(av_s2, pk);
     }
-    const int m = max(A, -Bm);
+    av_s2 L2[8], H2[8], L4[8], H4[8];               // min / max over 2 and over 4 consecutive ring positions
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const av_s2 nx = j < 7 ? D[j + 1] : s2_swap(D[0]); L2[j] = s2_min(D[j], nx); H2[j] = s2_max(D[j], nx); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        L4[j] = s2_min(L2[j], j < 6 ? L2[j + 2] : s2_swap(L2[j - 6]));
+        H4[j] = s2_max(H2[j], j < 6 ? H2[j + 2] : s2_swap(H2[j - 6]));
+    }
+    av_s2 A = {-256, -256}, Bm = {256, 256};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                   // windows of 9: positions i..i+3, i+4..i+7, i+8
+        const av_s2 far = s2_swap(D[j]);
+        const av_s2 lo9 = s2_min(s2_min(L4[j], j < 4 ? L4[j + 4] : s2_swap(L4[j - 4])), far);
+        const av_s2 hi9 = s2_max(s2_max(H4[j], j < 4 ? H4[j + 4] : s2_swap(H4[j - 4])), far);
+        A = s2_max(A, lo9);         // best arc of "centre brighter than ring by at least"
+        Bm = s2_min(Bm, hi9);       // best arc of "centre darker than ring by at least" (negated)
+    }
+    const int m = max(max((int)A.x, (int)A.y), -min((int)Bm.x, (int)Bm.y));
     return m > t ? m - 1 : 0;
 }
 
@@ -147,7 +163,6 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
                 // antipodal pair, so "centre brighter than one of (p0, p8) AND than one of (p4, p12)" -- or the same for darker --
                 // is necessary for a corner (OpenCV's own first rejection tests):
                 //   bright: min(max(d0, d8), max(d4, d12)) > t     dark: max(min(d0, d8), min(d4, d12)) < -t
-                typedef short av_s2 __attribute__((ext_vector_type(2)));
                 auto half = [](uint32_t x, int hi) -> av_s2 { return __builtin_bit_cast(av_s2, __builtin_amdgcn_perm(0, x, hi ? 0x0C030C02u : 0x0C010C00u)); };
                 const av_s2 tt = {(short)t, (short)t}, zz = {0, 0};
                 uint32_t fl[2];
@@ -210,17 +225,23 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
             const uint32_t A = rp[-1], Bm = rp[0], Cn = rp[1];
             lo[d] = __builtin_amdgcn_alignbyte(Bm, A, 3); hi[d] = __builtin_amdgcn_alignbyte(Cn, Bm, 3);
         }
+        // strict 3x3 maximum test for the four pixels at once, two pixels per register (packed u16): byte w of the 8-byte
+        // window (lo, hi) of a row is column pc - 1 + w; pixel k sees w = k (left), k + 1 (centre), k + 2 (right)
+        typedef unsigned short av_u2 __attribute__((ext_vector_type(2)));
+        auto pair = [&](int d, uint32_t sel) -> av_u2 { return __builtin_bit_cast(av_u2, __builtin_amdgcn_perm(hi[d], lo[d], sel)); };
+        constexpr uint32_t P01 = 0x0C010C00u, P12 = 0x0C020C01u, P23 = 0x0C030C02u, P34 = 0x0C040C03u, P45 = 0x0C050C04u;
+        auto mx3 = [](av_u2 x, av_u2 y, av_u2 z) -> av_u2 { return __builtin_elementwise_max(__builtin_elementwise_max(x, y), z); };
+        const av_u2 n01 = __builtin_elementwise_max(mx3(mx3(pair(0, P01), pair(0, P12), pair(0, P23)), pair(1, P01), pair(1, P23)),
+                                                    mx3(pair(2, P01), pair(2, P12), pair(2, P23)));
+        const av_u2 n23 = __builtin_elementwise_max(mx3(mx3(pair(0, P23), pair(0, P34), pair(0, P45)), pair(1, P23), pair(1, P45)),
+                                                    mx3(pair(2, P23), pair(2, P34), pair(2, P45)));
+        const av_u2 g01 = __builtin_elementwise_sub_sat(pair(1, P12), n01), g23 = __builtin_elementwise_sub_sat(pair(1, P34), n23);
+        const uint32_t gt[2] = {__builtin_bit_cast(uint32_t, g01), __builtin_bit_cast(uint32_t, g23)};      // half k & 1 of gt[k >> 1] != 0: score > all 8 neighbours
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int s = (int)((B >> (8 * k)) & 0xFF);
-            if (s == 0) continue;
             const int x = x0 + 4 * (q - 1) + k, y = y0 + r;
-            bool keep = x < a.w && y < a.h;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const uint32_t tri = (uint32_t)((((unsigned long long)hi[d] << 32) | lo[d]) >> (8 * k));       // bytes: left, centre, right
-                keep = keep && s > (int)(tri & 0xFF) && s > (int)((tri >> 16) & 0xFF) && (d == 1 || s > (int)((tri >> 8) & 0xFF));
-            }
+            bool keep = ((gt[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) != 0 && x < a.w && y < a.h;
             if (keep && a.mask) keep = mask_dw ? ((mask4[it] >> (8 * k)) & 0xFF) != 0 : a.mask[img_i * a.mask_stride + (size_t)y * a.w + x] != 0;
             if (keep && !(a.dbg & 8)) {
                 const int slot = atomicAdd(&nsurv, 1);            // LDS atomic; a tile has <= TCAP strict maxima
