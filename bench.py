@@ -389,6 +389,8 @@ def main():
                 poses0.append((k, flt.step(ids_h, uv_h, n_h, frame_ts[k])))
         msckf_s[0] += time.perf_counter() - t1
 
+    step_times = [] if os.environ.get('AV_BENCH_STEP_TIMES') else None     # diagnostic: wall time at which every frame's features were handed to the filter
+
     def run_pipelined(k_begin, k_end):
         """Full path for frames [k_begin, k_end), organised like the reference's VIO (vio.py:24-76: image thread ->
         feature queue -> filter thread): this thread drives the front-end and hands every frame's feature message to a
@@ -423,6 +425,8 @@ def main():
                     eng.read_features_begin((k + 1) & 1)
                 ids_h, uv_h, n_h = eng.read_features_end(k & 1)      # waits for frame k's copy only; fresh host arrays
                 q.put((k, ids_h, uv_h, n_h))
+                if step_times is not None:
+                    step_times.append((k, time.perf_counter()))
         finally:
             q.put(None)
             th.join()
@@ -472,10 +476,16 @@ def main():
     else:
         for k in range(T0, T0 + K):
             run(k)
+            if step_times is not None:
+                torch.cuda.synchronize()
+                step_times.append((k, time.perf_counter()))
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed)
     timing = eng.read_timing()
+    if step_times:
+        tt = [t for k, t in step_times if k >= T0]
+        sys.stderr.write('[step intervals ms] ' + ' '.join('%.1f' % ((b_ - a_) * 1e3) for a_, b_ in zip(tt[:-1], tt[1:])) + '\n')
     c_t1 = flt.counters() if flt is not None else None
     fe_elapsed = None
     timing_fe = None
