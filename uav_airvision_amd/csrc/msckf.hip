@@ -2072,7 +2072,8 @@ __global__ __launch_bounds__(UT) void update_back_kernel(UpdArgs a) { update_bac
 __global__ __launch_bounds__(UT) void update_front_batch_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list)
 {
     const UpdArgs a = arr[list ? list[blockIdx.x] : (int)blockIdx.x];  // block-uniform: lives in scalar registers
-    if (a.m > 0) update_front(a);
+    // (a listed stream may turn out not to compress: the chained path lists every stream that COULD exceed a chunk)
+    if (a.m > 0 && a.mode == 0 && a.kdir <= 0 && upd_compress(a.m, a.nc)) update_front(a);
 }
 // Streams whose stacked Jacobian is NOT compressed (upd_compress: at most 144 rows) only need the gated feature blocks
 // gathered into the transposed work matrix: a 256-thread workgroup, no QR machinery.
@@ -2119,6 +2120,7 @@ struct StackArgs {
     const UpdArgs* base;             // [S] per-stream constants (pointers, n, ld, ...); base.mode = 1: information form allowed
     UpdArgs* out;                    // [rounds][S]
     int S, rounds, cut1500, kch;
+    int compress;                    // 1: a stream with more than kch rows is QR-compressed (update_front_batch_kernel) and updated in ONE round
     int* stacked;                    // out [S]: rows stacked (0 = no update), -1 = more chunks than `rounds` (nothing is updated)
 };
 __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
@@ -2170,7 +2172,8 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
         int c = 0;
         for (int ci = 0; ci < 64; ++ci) if (used >> ci & 1ull) for (int e = 0; e < 6; ++e) a.cols[(size_t)s * a.cols_stride + c++] = IMU_DIM + 6 * ci + e;
         int nch = 0;
-        if (m > 0 && mode == 0) {                        // next-fit chunks of at most kch rows (a block is never split)
+        if (m > 0 && mode == 0 && a.compress) nch = 1;   // one round: direct if m <= kch, else thin QR to nc rows first
+        else if (m > 0 && mode == 0) {                   // next-fit chunks of at most kch rows (a block is never split)
             int acc = 0;
             s_chunk[nch++] = 0;
             for (int k = 0; k < nb; ++k) {
@@ -2190,7 +2193,10 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
         UpdArgs u = b;
         u.mode = mode; u.round = r; u.kdir = 0; u.nc = nc; u.cols = a.cols + (size_t)s * a.cols_stride;
         u.blk_row = a.blk_row + i0; u.blk_len = a.blk_len + i0; u.n_blk = nb; u.m = (too_many || overflow) ? 0 : m;
-        if (u.m > 0 && mode == 0) {
+        if (u.m > 0 && mode == 0 && a.compress) {
+            if (r > 0) u.m = 0;
+            else u.kdir = m <= a.kch ? m : 0;            // 0: k = upd_k(m, nc) = nc rows after the QR (m > kch >= nc compresses)
+        } else if (u.m > 0 && mode == 0) {
             if (r < nch) {
                 const int b0 = s_chunk[r], b1 = s_chunk[r + 1];
                 int rows = 0;
