@@ -96,15 +96,99 @@ def triangulation_vectors(ref_feature, ref_msckf, cfg, out):
     out['t_ok'] = np.array(res_ok)
 
 
-def run_filter(ref_msckf, cfg, seed, n_frames, n_features, full_P_at=()):
-    fs = SyntheticFeatureStream(cfg, seed=seed, n_frames=n_frames, n_features=n_features)
+class _Thr(np.float64):
+    """A chi-square threshold that notes what it is compared with.  gating_test (msckf.py:604-612) evaluates
+    `gamma < table[dof]` with gamma an np.float64; Python gives the reflected comparison of a SUBCLASS operand
+    precedence, so this __gt__ sees the reference's own gamma without touching its code or its result."""
+    sink = None
+
+    def __gt__(self, other):
+        res = float(other) < float(self)
+        if _Thr.sink is not None:
+            _Thr.sink.append((float(other), bool(res)))
+        return res
+
+
+def record_calls(ref_msckf, flt):
+    """Per-call outputs of the reference's gating_test / measurement_update / process_model:
+    gamma and the gate decision of every gated feature (msckf.py:604-612), delta_x, stacked shape and P+ of every
+    update (:548-602), P after every IMU sample (:275-339).  delta_x is a local of measurement_update; it is
+    recovered as the owner array of the slice handed to small_angle_quaternion at :576 (delta_x[:21][:3].base)."""
+    calls = dict(gamma=[], gate_ok=[], gate_dof=[], gate_frame=[],
+                 upd_frame=[], upd_m=[], upd_n=[], upd_dx=[], upd_Pdiag=[], upd_Ptrace=[], upd_P=[],
+                 pm_frame=[], pm_P11diag=[], pm_Ptrace=[], pm_P12fro=[], pm_P11=[])
+    cur = dict(frame=0, dx=None, in_update=False, n_pm=0)
+    sink = []
+    _Thr.sink = sink
+    flt.chi_squared_test_table = {k: _Thr(v) for k, v in flt.chi_squared_test_table.items()}
+    orig_gate, orig_upd, orig_pm = flt.gating_test, flt.measurement_update, flt.process_model
+    orig_saq = ref_msckf.small_angle_quaternion
+
+    def saq(dtheta):
+        if cur['in_update'] and cur['dx'] is None:
+            base = dtheta.base
+            assert base is not None and base.ndim == 1 and len(base) >= 21
+            cur['dx'] = np.array(base)
+        return orig_saq(dtheta)
+    ref_msckf.small_angle_quaternion = saq
+
+    def gate(H, r, dof):
+        n0 = len(sink)
+        ok = orig_gate(H, r, dof)
+        assert len(sink) == n0 + 1 and sink[-1][1] == bool(ok)
+        calls['gamma'].append(sink[-1][0]); calls['gate_ok'].append(bool(ok)); calls['gate_dof'].append(dof)
+        calls['gate_frame'].append(cur['frame'])
+        return ok
+
+    def upd(H, r):
+        if len(H) == 0 or len(r) == 0:
+            return orig_upd(H, r)
+        cur['in_update'], cur['dx'] = True, None
+        orig_upd(H, r)
+        cur['in_update'] = False
+        P = flt.state_server.state_cov
+        dx = np.zeros(21 + 6 * 30); dx[:len(cur['dx'])] = cur['dx']
+        pd = np.zeros(21 + 6 * 30); pd[:len(P)] = np.diag(P)
+        calls['upd_frame'].append(cur['frame']); calls['upd_m'].append(H.shape[0]); calls['upd_n'].append(H.shape[1])
+        calls['upd_dx'].append(dx); calls['upd_Pdiag'].append(pd); calls['upd_Ptrace'].append(np.trace(P))
+        if len(calls['upd_frame']) % 16 == 1:
+            calls['upd_P'].append((len(calls['upd_frame']) - 1, P.copy()))
+
+    def pm(time, m_gyro, m_acc):
+        orig_pm(time, m_gyro, m_acc)
+        P = flt.state_server.state_cov
+        calls['pm_frame'].append(cur['frame']); calls['pm_P11diag'].append(np.diag(P)[:21].copy())
+        calls['pm_Ptrace'].append(np.trace(P)); calls['pm_P12fro'].append(np.linalg.norm(P[:21, 21:]))
+        if cur['n_pm'] % 50 == 0:
+            calls['pm_P11'].append((cur['n_pm'], P[:21, :21].copy()))
+        cur['n_pm'] += 1
+    flt.gating_test, flt.measurement_update, flt.process_model = gate, upd, pm
+
+    def finish(out):
+        ref_msckf.small_angle_quaternion = orig_saq
+        _Thr.sink = None
+        for k in ('gamma', 'gate_ok', 'gate_dof', 'gate_frame', 'upd_frame', 'upd_m', 'upd_n', 'upd_dx', 'upd_Pdiag', 'upd_Ptrace',
+                  'pm_frame', 'pm_P11diag', 'pm_Ptrace', 'pm_P12fro'):
+            out['c_' + k] = np.array(calls[k])
+        for i, P in calls['upd_P']:
+            out['c_updP_%d' % i] = P
+        for i, P in calls['pm_P11']:
+            out['c_pmP11_%d' % i] = P
+    return cur, finish
+
+
+def run_filter(ref_msckf, cfg, seed, n_frames, n_features, full_P_at=(), calls=False, **kw):
+    fs = SyntheticFeatureStream(cfg, seed=seed, n_frames=n_frames, n_features=n_features, **kw)
     ref_msckf.IMUState.next_id = 0
     flt = ref_msckf.MSCKF(cfg)
+    cur, finish = record_calls(ref_msckf, flt) if calls else (None, None)
     rec = {k: [] for k in ('t', 'q', 'p', 'v', 'bg', 'ba', 'R_ic', 't_ci', 'Pdiag', 'Ptrace', 'ncam', 'nmap', 'published')}
     fullP = {}
     frame = [0]
 
     def on(msg):
+        if cur is not None:
+            cur['frame'] = frame[0]
         res = flt.feature_callback(msg)
         s = flt.state_server.imu_state
         P = flt.state_server.state_cov
@@ -122,10 +206,13 @@ def run_filter(ref_msckf, cfg, seed, n_frames, n_features, full_P_at=()):
     for k, P in fullP.items():
         out['P_%d' % k] = P
     out['gravity'] = np.array(ref_msckf.IMUState.gravity)
+    if finish is not None:
+        finish(out)
     return out
 
 
 def main():
+    only_new = '--all' not in sys.argv              # the round-1 files are left alone unless --all is given
     cfg = ConfigEuRoC()
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as tmp:
@@ -133,20 +220,33 @@ def main():
         try:
             with contextlib.redirect_stdout(io.StringIO()):
                 ref_msckf, ref_utils, ref_feature = import_reference()
-                u = {}
-                utils_vectors(ref_utils, u)
-                triangulation_vectors(ref_feature, ref_msckf, cfg, u)
-                e1 = run_filter(ref_msckf, cfg, seed=0, n_frames=150, n_features=100, full_P_at=(25, 60, 149))
-                e2 = run_filter(ref_msckf, cfg, seed=3, n_frames=45, n_features=300, full_P_at=(44,))
+                if not only_new:
+                    u = {}
+                    utils_vectors(ref_utils, u)
+                    triangulation_vectors(ref_feature, ref_msckf, cfg, u)
+                    e1 = run_filter(ref_msckf, cfg, seed=0, n_frames=150, n_features=100, full_P_at=(25, 60, 149))
+                    e2 = run_filter(ref_msckf, cfg, seed=3, n_frames=45, n_features=300, full_P_at=(44,))
+                # round 3: per-call vectors (gamma, delta_x, P+, process_model P) along a run that prunes, and the
+                # configs[4] shape: 1,500 features per frame (the > 1500 rows cut msckf.py:667-668, the uncapped
+                # camera-pruning update :712-786)
+                c1 = run_filter(ref_msckf, cfg, seed=5, n_frames=60, n_features=100, full_P_at=(59,), calls=True, outlier_rate=0.02)
+                c2 = run_filter(ref_msckf, cfg, seed=9, n_frames=30, n_features=1500, full_P_at=(29,), calls=True, outlier_rate=0.005)
         finally:
             os.chdir(cwd)
     gdir = os.path.join(ROOT, 'tests', 'golden')
-    np.savez_compressed(os.path.join(gdir, 'msckf_units.npz'), **u)
-    np.savez_compressed(os.path.join(gdir, 'msckf_e2e_seed0_n100.npz'), seed=0, n_frames=150, n_features=100, **e1)
-    np.savez_compressed(os.path.join(gdir, 'msckf_e2e_seed3_n300.npz'), seed=3, n_frames=45, n_features=300, **e2)
-    print('units:', {k: v.shape for k, v in u.items()})
-    print('e2e n100: published', int(e1['published'].sum()), 'ncam max', int(e1['ncam'].max()), 'P trace last', float(e1['Ptrace'][-1]))
-    print('e2e n300: published', int(e2['published'].sum()), 'ncam max', int(e2['ncam'].max()))
+    if not only_new:
+        np.savez_compressed(os.path.join(gdir, 'msckf_units.npz'), **u)
+        np.savez_compressed(os.path.join(gdir, 'msckf_e2e_seed0_n100.npz'), seed=0, n_frames=150, n_features=100, **e1)
+        np.savez_compressed(os.path.join(gdir, 'msckf_e2e_seed3_n300.npz'), seed=3, n_frames=45, n_features=300, **e2)
+        print('units:', {k: v.shape for k, v in u.items()})
+        print('e2e n100: published', int(e1['published'].sum()), 'ncam max', int(e1['ncam'].max()), 'P trace last', float(e1['Ptrace'][-1]))
+        print('e2e n300: published', int(e2['published'].sum()), 'ncam max', int(e2['ncam'].max()))
+    c2 = {k: v for k, v in c2.items() if not k.startswith('c_pm')}          # the IMU part is the same code at any feature count
+    np.savez_compressed(os.path.join(gdir, 'msckf_calls_seed5_n100.npz'), seed=5, n_frames=60, n_features=100, outlier_rate=0.02, **c1)
+    np.savez_compressed(os.path.join(gdir, 'msckf_calls_seed9_n1500.npz'), seed=9, n_frames=30, n_features=1500, outlier_rate=0.005, **c2)
+    for name, c in (('calls n100', c1), ('calls n1500', c2)):
+        print(name, 'gates', len(c['c_gamma']), 'passed', int(c['c_gate_ok'].sum()), 'updates', len(c['c_upd_m']),
+              'rows max', int(c['c_upd_m'].max()), 'cols max', int(c['c_upd_n'].max()), 'ncam max', int(c['ncam'].max()))
 
 
 if __name__ == '__main__':

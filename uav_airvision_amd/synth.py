@@ -219,7 +219,8 @@ class SyntheticFeatureStream(object):
     U{3..24} frames, pixel noise sigma ~0.5 px (MSCKF microbench recipe).
     `frames()` yields feature_msg(timestamp, [FeatureMeasurement-like]); `imu` as SyntheticStream."""
 
-    def __init__(self, config, seed=0, n_frames=100, n_features=100, pixel_sigma=0.5, motion_scale=1.0, t0=100.0):
+    def __init__(self, config, seed=0, n_frames=100, n_features=100, pixel_sigma=0.5, motion_scale=1.0, t0=100.0,
+                 outlier_rate=0.0, outlier_px=12.0):
         self.base = SyntheticStream(config, seed=seed, n_frames=n_frames, motion_scale=motion_scale, t0=t0, render=False)
         self.config = config
         self.n_frames = n_frames
@@ -227,6 +228,10 @@ class SyntheticFeatureStream(object):
         self.imu = self.base.imu
         self.rng = np.random.default_rng(0xFEA7 + seed)
         self.sigma = pixel_sigma / float(config.cam0_intrinsics[0])
+        # gross mismatches (so that the chi-square gate rejects something); own generator: rate 0 leaves the stream as it was
+        self.outlier_rate = outlier_rate
+        self.outlier_sigma = outlier_px / float(config.cam0_intrinsics[0])
+        self.rng_out = np.random.default_rng(0x0071 + seed)
         self.T_c0_i = self.base.T_c0_i
         self.T_c1_i = self.base.T_c1_i
         self._next_id = 0
@@ -257,6 +262,8 @@ class SyntheticFeatureStream(object):
                 tr[2] = 0
                 continue
             n = self.rng.normal(0, self.sigma, 4)
+            if self.outlier_rate > 0 and self.rng_out.random() < self.outlier_rate:
+                n = n + self.rng_out.normal(0, self.outlier_sigma, 4)
             m = _Meas()
             m.id = tr[0]
             m.u0, m.v0 = q0[0] / q0[2] + n[0], q0[1] / q0[2] + n[1]
