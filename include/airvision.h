@@ -234,6 +234,21 @@ int  av_msckf_update(av_msckf* ctx, const int32_t* blk_row_dev, const int32_t* b
                      double obs_noise, double* dx_host, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Quaternion / rotation helpers of the filter, for host callers (replaces the functions of src/utils.py; JPL
+ * quaternions [x, y, z, w]).  Pure host functions (no device needed); rotation matrices are 9 doubles, row-major.
+ *   av_quat_to_rotation       to_rotation(q)                   utils.py:12-23   (normalises q first)
+ *   av_rotation_to_quat       to_quaternion(R)                 utils.py:25-47
+ *   av_quat_multiply          quaternion_multiplication(a, b)  utils.py:61-76   (normalises inputs and output)
+ *   av_quat_small_angle       small_angle_quaternion(dtheta)   utils.py:79-93   (|dtheta/2|^2 <= 1 branch rule)
+ *   av_quat_from_two_vectors  from_two_vectors(v0, v1)         utils.py:96-120  (antiparallel / parallel fallbacks)
+ * ------------------------------------------------------------------------------------------- */
+int  av_quat_to_rotation(const double q[4], double R_rowmajor9[9]);
+int  av_rotation_to_quat(const double R_rowmajor9[9], double q[4]);
+int  av_quat_multiply(const double q1[4], const double q2[4], double out[4]);
+int  av_quat_small_angle(const double dtheta[3], double q[4]);
+int  av_quat_from_two_vectors(const double v0[3], const double v1[3], double q[4]);
+
+/* ---------------------------------------------------------------------------------------------
  * n_streams independent MSCKF filters stepped together (the throughput path of the back-end).  The
  * bookkeeping of MSCKF.feature_callback (msckf.py:177-228) runs in C++ inside the library for all
  * streams; each numeric phase is one batched launch over all streams (same kernels as av_msckf_*).
@@ -251,13 +266,16 @@ void av_msckf_batch_destroy(av_msckf_batch* b);
 /* MSCKF.imu_callback for n samples (msckf.py:162-175 incl. initialize_gravity_and_bias); gyro/acc are [n][3]. */
 int  av_msckf_batch_push_imu(av_msckf_batch* b, const int32_t* stream_idx, const double* timestamps, const double* gyro, const double* acc, int n);
 /* MSCKF.feature_callback for every stream.  Host inputs: stream s has n_feat[s] features, ids[s*cap+k],
- * uv[(s*cap+k)*4..] = u0 v0 u1 v1.  out[s*12..] = {published (0/1), t, p[3], q[4] (JPL xyzw), v[3]}.
+ * uv[(s*cap+k)*4..] = u0 v0 u1 v1.  out[s*12..] = {published (0/1; -1 = stream stopped, av_msckf_batch_stream_status),
+ * t, p[3], q[4] (JPL xyzw), v[3]}.
  * A stream is live for a frame iff its gravity initialisation was completed by an IMU sample not newer than the frame
  * (msckf.py:182-183 under the deterministic replay); timestamps[s] < 0 means "no frame for stream s in this
  * step" (sequences of different lengths stepped together): the stream idles and reports published = 0.
  * The first step fixes the message capacity `cap` the device buffers are sized for; rows_cap must be >= 5*cap
  * (camera-pruning update) and >= 1664 (lost-feature update: 1500-row cut + one block), else AV_E_CAPACITY;
- * rows_cap = 0 at create sizes the block buffers from that first `cap` (max(2048, 5*cap + 64) rows). */
+ * rows_cap = 0 at create sizes the block buffers from that first `cap` (max(2048, 5*cap + 64) rows): the FIRST step's cap is
+ * binding -- a later step with a larger cap fails with AV_E_CAPACITY unless rows_cap was given explicitly.
+ * max_cam_states <= 24 (one back-end pass holds 144 columns = 6 per camera state); the reference's value is 20. */
 int  av_msckf_batch_step(av_msckf_batch* b, const int64_t* ids, const double* uv, const int32_t* n_feat, int cap,
                          const double* timestamps, double* out, void* stream);
 /* The same step, queued: returns at once; the stream groups of the batch consume their queues independently (a group
@@ -272,6 +290,18 @@ int  av_msckf_batch_submit(av_msckf_batch* b, const int64_t* ids, const double* 
 int  av_msckf_batch_wait(av_msckf_batch* b, int max_pending);
 int  av_msckf_batch_get_cov(av_msckf_batch* b, int stream_idx, double* P_host, int n, void* stream);
 int  av_msckf_batch_sizes(av_msckf_batch* b, int stream_idx, int32_t out3[3]);     /* [state dim, camera states, map features] */
+/* Full host-side state of one stream -- every target of measurement_update's injection (msckf.py:568-595), for parity tests
+ * (SURVEY 8b get_state): imu32 = [imu_state.timestamp, orientation q(4, JPL xyzw), position(3), velocity(3), gyro_bias(3),
+ * acc_bias(3), R_imu_cam0 (9, row-major), t_cam0_imu(3), IMUState.gravity(3)]; the camera states of the window in
+ * state_server.cam_states order: cam_ids[k] and cam_qp7[7k..] = orientation(4), position(3).  *n_cam = their number;
+ * cam_cap = 0 only asks for imu32 and the count.  Drain (wait 0) first. */
+int  av_msckf_batch_get_state(av_msckf_batch* b, int stream_idx, double imu32[32], int64_t* cam_ids, double* cam_qp7, int cam_cap, int32_t* n_cam);
+/* A failure that concerns ONE stream (its camera window or the block list of one of its updates outgrew a fixed capacity)
+ * stops that stream only: from then on it idles and its out[s*12] reads -1; the other streams of the batch keep stepping
+ * (the reference's sequences are separate processes, run.bat:4-12).  *status = 0 while the stream runs, else the
+ * AV_E_* code that stopped it, with the reason in msg.  Configuration errors (rows_cap vs cap, LDS limits) and HIP errors
+ * concern the whole batch and are returned by the step / wait as before. */
+int  av_msckf_batch_stream_status(av_msckf_batch* b, int stream_idx, int32_t* status, char* msg, int msg_cap);
 /* Run statistics over all streams (drain first): [steps, stream-steps that ran prune_cam_state_buffer (msckf.py:712-786),
  * streams whose lost features were gated in two passes because their candidates outgrew rows_cap, device-buffer
  * reallocations after the first step (0 in a correctly pre-sized run), min camera states, max camera states,

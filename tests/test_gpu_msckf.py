@@ -172,6 +172,17 @@ def test_batched_filters_match_reference_golden_and_oracle(cfg, groups, monkeypa
             err = max(np.abs(out[i, 2:5] - s.position).max(), np.abs(out[i, 5:9] - s.orientation).max(), np.abs(out[i, 9:12] - s.velocity).max())
             worst = max(worst, err)
             assert err < 1e-6, (k, i, err)
+            # every target of the state injection (msckf.py:576-595): biases, extrinsics, the camera states of the window
+            gs = bat.get_state(i)
+            assert np.abs(gs['bg'] - s.gyro_bias).max() < 1e-7 and np.abs(gs['ba'] - s.acc_bias).max() < 1e-6, (k, i)
+            assert np.abs(gs['R_ic'] - s.R_imu_cam0).max() < 1e-6 and np.abs(gs['t_ci'] - s.t_cam0_imu).max() < 1e-6, (k, i)
+            assert list(gs['cam_ids']) == list(oras[i].cam_states.keys()), (k, i)
+            if len(gs['cam_ids']):
+                assert np.abs(gs['cam_q'] - np.array([c.orientation for c in oras[i].cam_states.values()])).max() < 1e-6
+                assert np.abs(gs['cam_p'] - np.array([c.position for c in oras[i].cam_states.values()])).max() < 1e-6
+            if i == 0 and out[0, 0]:       # stream 0 against the REFERENCE's own run (golden)
+                assert np.abs(gs['bg'] - g['bg'][k]).max() < 1e-7 and np.abs(gs['ba'] - g['ba'][k]).max() < 1e-6, k
+                assert np.abs(gs['R_ic'] - g['R_ic'][k]).max() < 1e-6 and np.abs(gs['t_ci'] - g['t_ci'][k]).max() < 1e-6, k
         # out[., 1] is imu_state.timestamp (msckf.py:268: the last IMU sample integrated, <= one IMU period before the frame)
         assert 0.0 <= g['t'][k] - out[0, 1] < 0.0051
         assert np.abs(out[0, 2:5] - g['p'][k]).max() < 1e-6 and np.abs(out[0, 5:9] - g['q'][k]).max() < 1e-6
@@ -572,4 +583,102 @@ def test_batched_filter_matches_reference_golden_at_1500_features(cfg):
         assert err < 1e-6, (k, err)
     last = 'P_%d' % (st.n_frames - 1)
     assert np.abs(bat.get_cov(0) - g[last]).max() <= 1e-6 * np.abs(g[last]).max()
+    bat.close()
+
+
+def _feed(bat, oras, streams, its, pend, k, cap):
+    """One frame of every stream into the batch (and the IMU samples up to it into batch + oracles)."""
+    S = len(streams)
+    msgs = [st.frame(k) if k < st.n_frames else None for st in streams]
+    si, ts, gy, ac = [], [], [], []
+    for i, m in enumerate(msgs):
+        while m is not None and pend[i] is not None and pend[i].timestamp <= m.timestamp:
+            if oras[i] is not None:
+                oras[i].imu_callback(pend[i])
+            si.append(i); ts.append(pend[i].timestamp); gy.append(pend[i].angular_velocity); ac.append(pend[i].linear_acceleration)
+            pend[i] = next(its[i], None)
+    if si:
+        bat.push_imu(si, ts, gy, ac)
+    ids = np.zeros((S, cap), np.int64); uv = np.zeros((S, cap, 4)); nf = np.zeros(S, np.int32); tt = np.full(S, -1.0)
+    for i, m in enumerate(msgs):
+        if m is None:
+            continue
+        nf[i] = len(m.features); tt[i] = m.timestamp
+        ids[i, :nf[i]] = [f.id for f in m.features]
+        uv[i, :nf[i]] = [(f.u0, f.v0, f.u1, f.v1) for f in m.features]
+    return msgs, bat.step(ids, uv, nf, tt)
+
+
+def test_batched_filter_window_of_24_camera_states_and_the_limit():
+    """one back-end pass holds 144 columns = 24 camera states.  At max_cam_state_size = 24 long lost-feature
+    updates (m > 144, n_c up to 138) must follow the oracle; 25 and more are refused at create, not computed wrongly."""
+    from oracle.msckf_np import OracleMSCKF
+    from uav_airvision_amd._native import AirvisionError
+    from uav_airvision_amd.config import ConfigEuRoC
+    from uav_airvision_amd.msckf_ops import BatchedMSCKF
+    from uav_airvision_amd.synth import SyntheticFeatureStream
+    cfg = ConfigEuRoC()
+    cfg.max_cam_state_size = 28
+    with pytest.raises(AirvisionError, match='max_cam_states'):
+        BatchedMSCKF(cfg, 1)
+    cfg.max_cam_state_size = 24
+    n_frames = 60
+    streams = [SyntheticFeatureStream(cfg, seed=81, n_frames=n_frames, n_features=150), SyntheticFeatureStream(cfg, seed=82, n_frames=n_frames, n_features=60)]
+    bat = BatchedMSCKF(cfg, 2)
+    oras = [OracleMSCKF(cfg), OracleMSCKF(cfg)]
+    its = [iter(s.imu) for s in streams]; pend = [next(it, None) for it in its]
+    big = 0
+    for k in range(n_frames):
+        msgs, out = _feed(bat, oras, streams, its, pend, k, 256)
+        for i, m in enumerate(msgs):
+            oras[i].debug.pop('delta_x', None)
+            r = oras[i].feature_callback(m)
+            assert (r is not None) == bool(out[i, 0])
+            if r is None:
+                continue
+            s = oras[i].imu_state
+            assert bat.sizes(i) == (oras[i].state_cov.shape[0], len(oras[i].cam_states), len(oras[i].map_server)), (k, i)
+            err = max(np.abs(out[i, 2:5] - s.position).max(), np.abs(out[i, 5:9] - s.orientation).max(), np.abs(out[i, 9:12] - s.velocity).max())
+            assert err < 1e-6, (k, i, err)
+            big = max(big, oras[i].state_cov.shape[0])
+    assert big >= 21 + 6 * 23                                    # the window really grew to 23+ camera states
+    for i in range(2):
+        Po = oras[i].state_cov
+        assert np.abs(bat.get_cov(i) - Po).max() <= 1e-6 * np.abs(Po).max()
+    bat.close()
+
+
+def test_one_streams_capacity_failure_does_not_stop_the_others(cfg):
+    """stream 0 publishes 4,300 features per frame; its first camera-pruning update stacks more blocks
+    than the back end's block list holds (4,096), which stops THAT stream (published = -1, stream_status says why).
+    Stream 1 of the same group must keep following the oracle to the end."""
+    from oracle.msckf_np import OracleMSCKF
+    from uav_airvision_amd._native import AV_E_CAPACITY
+    from uav_airvision_amd.msckf_ops import BatchedMSCKF
+    from uav_airvision_amd.synth import SyntheticFeatureStream
+    n_frames = 40
+    streams = [SyntheticFeatureStream(cfg, seed=91, n_frames=24, n_features=4300), SyntheticFeatureStream(cfg, seed=92, n_frames=n_frames, n_features=100)]
+    bat = BatchedMSCKF(cfg, 2, max_features=4352)
+    oras = [None, OracleMSCKF(cfg)]
+    its = [iter(s.imu) for s in streams]; pend = [next(it, None) for it in its]
+    failed_at = None
+    for k in range(n_frames):
+        msgs, out = _feed(bat, oras, streams, its, pend, k, 4352)
+        if out[0, 0] < 0 and failed_at is None:
+            failed_at = k
+        if failed_at is not None and msgs[0] is not None:
+            assert out[0, 0] == -1.0
+        r = oras[1].feature_callback(msgs[1])
+        assert (r is not None) == (out[1, 0] == 1.0), k
+        if r is not None:
+            s = oras[1].imu_state
+            err = max(np.abs(out[1, 2:5] - s.position).max(), np.abs(out[1, 5:9] - s.orientation).max(), np.abs(out[1, 9:12] - s.velocity).max())
+            assert err < 1e-6, (k, err)
+            assert bat.sizes(1) == (oras[1].state_cov.shape[0], len(oras[1].cam_states), len(oras[1].map_server)), k
+    assert failed_at is not None and 15 <= failed_at <= 23
+    code, msg = bat.stream_status(0)
+    assert code == AV_E_CAPACITY and 'blocks' in msg
+    assert bat.stream_status(1) == (0, '')
+    Po = oras[1].state_cov
+    assert np.abs(bat.get_cov(1) - Po).max() <= 1e-6 * np.abs(Po).max()
     bat.close()

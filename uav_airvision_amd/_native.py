@@ -92,6 +92,13 @@ SIGNATURES = {
     'av_msckf_batch_get_cov': (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     'av_msckf_batch_sizes': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32 * 3)]),
     'av_msckf_batch_counters': (C.c_int, [_P, C.POINTER(C.c_int64 * 8)]),
+    'av_quat_to_rotation': (C.c_int, [_P, _P]),
+    'av_rotation_to_quat': (C.c_int, [_P, _P]),
+    'av_quat_multiply': (C.c_int, [_P, _P, _P]),
+    'av_quat_small_angle': (C.c_int, [_P, _P]),
+    'av_quat_from_two_vectors': (C.c_int, [_P, _P, _P]),
+    'av_msckf_batch_get_state': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double * 32), _P, _P, C.c_int, C.POINTER(C.c_int32)]),
+    'av_msckf_batch_stream_status': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_char_p, C.c_int]),
     'av_frontend_enable_timing': (C.c_int, [_P, C.c_int]),
     'av_frontend_read_timing': (C.c_int, [_P, C.POINTER(C.c_double * 4), C.POINTER(C.c_int32 * 4)]),
 }

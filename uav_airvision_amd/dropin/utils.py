@@ -1,100 +1,90 @@
-"""Quaternion / SE3 helpers with the reference's names and conventions (reference: src/utils.py:2-141;
-JPL quaternions [x, y, z, w], `to_rotation(q)` maps world -> body).  Host-side scalar math only;
-everything matrix-sized runs in libairvision_hip.so."""
+"""`utils` of the drop-in: the names modules importing the reference's src/utils.py expect, served by the
+library's own host helpers (include/airvision.h, av_quat_* -- the same C++ the batched filter runs), so the
+JPL-quaternion formulas exist once.  numpy in, numpy out; every wrapper raises on a library error."""
+import ctypes as C
+
 import numpy as np
 
+from uav_airvision_amd import _native as N
 
-def skew(vec):
-    x, y, z = vec
-    return np.array([[0, -z, y], [z, 0, -x], [-y, x, 0]])
+
+def _vec(a, n):
+    v = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+    if v.size != n:
+        raise ValueError('expected %d values, got %d' % (n, v.size))
+    return v
+
+
+def _call(name, out_shape, *args):
+    out = np.empty(out_shape)
+    ptrs = [a.ctypes.data_as(C.c_void_p) for a in args] + [out.ctypes.data_as(C.c_void_p)]
+    N.check(getattr(N.lib(), name)(*ptrs))
+    return out
 
 
 def to_rotation(q):
-    """utils.py:12-23 (re-normalises q on every call)."""
-    q = q / np.linalg.norm(q)
-    vec, w = q[:3], q[3]
-    return (2 * w * w - 1) * np.identity(3) - 2 * w * skew(vec) + 2 * vec[:, None] * vec
+    """C(q), world -> body for a JPL quaternion (reference: utils.py:12-23)."""
+    return _call('av_quat_to_rotation', (3, 3), _vec(q, 4))
 
 
 def to_quaternion(R):
-    """utils.py:25-47."""
-    if R[2, 2] < 0:
-        if R[0, 0] > R[1, 1]:
-            q = [1 + R[0, 0] - R[1, 1] - R[2, 2], R[0, 1] + R[1, 0], R[2, 0] + R[0, 2], R[1, 2] - R[2, 1]]
-        else:
-            q = [R[0, 1] + R[1, 0], 1 - R[0, 0] + R[1, 1] - R[2, 2], R[2, 1] + R[1, 2], R[2, 0] - R[0, 2]]
-    elif R[0, 0] < -R[1, 1]:
-        q = [R[0, 2] + R[2, 0], R[2, 1] + R[1, 2], 1 - R[0, 0] - R[1, 1] + R[2, 2], R[0, 1] - R[1, 0]]
-    else:
-        q = [R[1, 2] - R[2, 1], R[2, 0] - R[0, 2], R[0, 1] - R[1, 0], 1 + R[0, 0] + R[1, 1] + R[2, 2]]
-    q = np.array(q)
-    return q / np.linalg.norm(q)
-
-
-def quaternion_normalize(q):
-    return q / np.linalg.norm(q)
-
-
-def quaternion_conjugate(q):
-    return np.array([*-q[:3], q[3]])
+    """Unit JPL quaternion of a rotation matrix (reference: utils.py:25-47)."""
+    return _call('av_rotation_to_quat', 4, _vec(R, 9))
 
 
 def quaternion_multiplication(q1, q2):
-    """utils.py:61-76."""
-    q1 = q1 / np.linalg.norm(q1)
-    q2 = q2 / np.linalg.norm(q2)
-    L = np.array([[q1[3], q1[2], -q1[1], q1[0]],
-                  [-q1[2], q1[3], q1[0], q1[1]],
-                  [q1[1], -q1[0], q1[3], q1[2]],
-                  [-q1[0], -q1[1], -q1[2], q1[3]]])
-    q = L @ q2
-    return q / np.linalg.norm(q)
+    """q1 (x) q2, inputs and output normalised (reference: utils.py:61-76)."""
+    return _call('av_quat_multiply', 4, _vec(q1, 4), _vec(q2, 4))
 
 
 def small_angle_quaternion(dtheta):
-    """utils.py:79-93."""
-    dq = dtheta / 2.
-    n2 = dq @ dq
-    if n2 <= 1:
-        return np.array([*dq, np.sqrt(1 - n2)])
-    q = np.array([*dq, 1.])
-    return q / np.sqrt(1 + n2)
+    """Quaternion of a small rotation vector (reference: utils.py:79-93)."""
+    return _call('av_quat_small_angle', 4, _vec(dtheta, 3))
 
 
 def from_two_vectors(v0, v1):
-    """utils.py:96-120."""
-    v0 = v0 / np.linalg.norm(v0)
-    v1 = v1 / np.linalg.norm(v1)
-    d = v0 @ v1
-    if d < -0.999999:
-        axis = np.cross([1, 0, 0], v0)
-        if np.linalg.norm(axis) < 0.000001:
-            axis = np.cross([0, 1, 0], v0)
-        q = np.array([*axis, 0.])
-    elif d > 0.999999:
-        q = np.array([0., 0., 0., 1.])
-    else:
-        s = np.sqrt((1 + d) * 2)
-        q = np.array([*(np.cross(v0, v1) / s), 0.5 * s])
-    q = q / np.linalg.norm(q)
-    return quaternion_conjugate(q)
+    """Quaternion taking direction v0 to v1 (reference: utils.py:96-120)."""
+    return _call('av_quat_from_two_vectors', 4, _vec(v0, 3), _vec(v1, 3))
+
+
+def quaternion_normalize(q):
+    q = np.asarray(q, dtype=np.float64)
+    return q / np.sqrt(np.dot(q, q))
+
+
+def quaternion_conjugate(q):
+    return np.asarray(q, dtype=np.float64) * np.array([-1.0, -1.0, -1.0, 1.0])
+
+
+def skew(vec):
+    """[v]x: skew(v) @ w == cross(v, w)."""
+    m = np.zeros((3, 3))
+    m[[2, 0, 1], [1, 2, 0]] = vec
+    m[[1, 2, 0], [2, 0, 1]] = np.negative(vec)
+    return m
 
 
 class Isometry3d(object):
-    """utils.py:124-141."""
+    """Rigid transform x -> R x + t (reference: utils.py:124-141; modules/viewer.py reads `.t`, the filter `.R`)."""
+    __slots__ = ('R', 't')
 
     def __init__(self, R, t):
-        self.R = R
-        self.t = t
+        self.R, self.t = R, t
+
+    @classmethod
+    def from_matrix(cls, T):
+        T = np.asarray(T, dtype=np.float64)
+        return cls(T[:3, :3].copy(), T[:3, 3].copy())
 
     def matrix(self):
-        m = np.identity(4)
-        m[:3, :3] = self.R
-        m[:3, 3] = self.t
-        return m
+        return np.block([[np.asarray(self.R, dtype=np.float64), np.reshape(self.t, (3, 1))], [np.zeros((1, 3)), np.ones((1, 1))]])
 
     def inverse(self):
-        return Isometry3d(self.R.T, -self.R.T @ self.t)
+        Rt = np.transpose(self.R)
+        return Isometry3d(Rt, np.negative(np.dot(Rt, self.t)))
 
-    def __mul__(self, T1):
-        return Isometry3d(self.R @ T1.R, self.R @ T1.t + self.t)
+    def __mul__(self, other):
+        return Isometry3d(np.dot(self.R, other.R), np.dot(self.R, other.t) + self.t)
+
+    def __repr__(self):
+        return 'Isometry3d(R=%r, t=%r)' % (self.R, self.t)

@@ -155,7 +155,9 @@ class BatchedMSCKF(object):
     def __init__(self, config, n_streams, device=0, rows_cap=None, max_features=None):
         """rows_cap: rows of the per-stream block buffer.  None = sized by the library from the capacity of the first
         feature message (the camera-pruning update stacks 5 rows per feature, the lost-feature update at most 1500 + one
-        block); `max_features`, when given, sizes it up front instead."""
+        block); `max_features`, when given, sizes it up front instead.  With the automatic size the FIRST step's
+        `ids.shape[1]` is binding: a later step with a wider array raises AV_E_CAPACITY -- pass max_features (or rows_cap)
+        when the width of the feature arrays can vary.  config.max_cam_state_size <= 24 (reference: 20)."""
         if rows_cap is None:
             rows_cap = 0 if max_features is None else max(2048, 5 * int(max_features) + 64)
         self.rows_cap = int(rows_cap)
@@ -259,3 +261,24 @@ class BatchedMSCKF(object):
         with torch.cuda.device(self.device):
             N.check(N.lib().av_msckf_batch_get_cov(self._h, int(s), P.ctypes.data_as(C.c_void_p), n, N.current_stream()))
         return P
+
+    def get_state(self, s):
+        """Everything measurement_update injects into (msckf.py:568-595) for stream s: dict(t, q, p, v, bg, ba, R_ic, t_ci,
+        gravity, cam_ids, cam_q, cam_p).  Drain (`wait(0)`) first."""
+        imu = (C.c_double * 32)()
+        n = C.c_int32(0)
+        cap = int(self.config.max_cam_state_size) + 1
+        ids = np.zeros(cap, np.int64); qp = np.zeros((cap, 7))
+        N.check(N.lib().av_msckf_batch_get_state(self._h, int(s), C.byref(imu), ids.ctypes.data_as(C.c_void_p), qp.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        a = np.array(imu[:])
+        k = int(n.value)
+        return dict(t=a[0], q=a[1:5], p=a[5:8], v=a[8:11], bg=a[11:14], ba=a[14:17], R_ic=a[17:26].reshape(3, 3), t_ci=a[26:29],
+                    gravity=a[29:32], cam_ids=ids[:k].copy(), cam_q=qp[:k, :4].copy(), cam_p=qp[:k, 4:].copy())
+
+    def stream_status(self, s):
+        """(0, '') while stream s runs; (AV_E_* code, reason) once a per-stream capacity failure stopped it (its step output
+        then reads published = -1; the other streams keep running)."""
+        st = C.c_int32(0)
+        msg = C.create_string_buffer(160)
+        N.check(N.lib().av_msckf_batch_stream_status(self._h, int(s), C.byref(st), msg, 160))
+        return int(st.value), msg.value.decode()
