@@ -152,6 +152,14 @@ int av_frontend_step(av_frontend* fe, const uint8_t* img0_dev, const uint8_t* im
 int av_frontend_step_host(av_frontend* fe, const uint8_t* img0_host, const uint8_t* img1_host, int64_t img_stride,
                           const double* timestamps, void* stream);
 
+/* Host-side staging for sweeps: decode n 8-bit greyscale, non-interlaced PNG files of width x height (the EuRoC camera
+ * frames; reference: streaming/dataset.py:101 `cv2.imread(path, -1)` on the reader threads of dataset.py:93-158) on
+ * `threads` host threads, file i into out + i*out_stride -- e.g. straight into the [S][h][w] batches handed to
+ * av_frontend_step_host, one step ahead of the GPU.  status[i] (optional) = 0 ok, 1 unsupported flavour of PNG (other depth /
+ * colour type / size / interlaced: the caller may decode that file by other means), 2 unreadable or corrupt.  Returns AV_OK,
+ * AV_E_CAPACITY if the worst status is 1, AV_E_INVALID if any file was unreadable.  Pure host function. */
+int av_png_decode_gray8(const char* const* paths, int n, int width, int height, uint8_t* out, int64_t out_stride, int threads, int32_t* status);
+
 /* Capacity (features per stream) of the published feature message = grid_num * grid_max. */
 int av_frontend_max_features(const av_frontend* fe);
 

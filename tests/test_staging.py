@@ -1,0 +1,106 @@
+"""Host-side staging of sweeps: the library's threaded PNG decoder (av_png_decode_gray8) against Pillow, and
+the one-step-ahead frame stager on EuRoC-layout directories.  Host code only: no GPU needed."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from uav_airvision_amd import _native as N
+from uav_airvision_amd.euroc import EuRoCDataset, FrameStager, decode_batch, read_image
+
+
+def _images(rng, n, h=480, w=752):
+    out = []
+    for i in range(n):
+        kind = i % 4
+        if kind == 0:
+            a = rng.integers(0, 256, (h, w), dtype=np.uint8)                        # noise: filter 0 / mixed
+        elif kind == 1:
+            a = (np.add.outer(np.arange(h), np.arange(w)) // 3 % 256).astype(np.uint8)     # ramps: Sub / Up / Paeth rows
+        elif kind == 2:
+            a = np.clip(128 + 60 * np.sin(np.arange(w) / 17.0)[None, :] + rng.normal(0, 3, (h, w)), 0, 255).astype(np.uint8)
+        else:
+            a = np.zeros((h, w), np.uint8); a[h // 3:, w // 4:] = 200
+        out.append(a)
+    return out
+
+
+def test_png_decoder_matches_pillow_on_every_filter_type(tmp_path):
+    rng = np.random.default_rng(3)
+    imgs = _images(rng, 12)
+    paths = []
+    for i, a in enumerate(imgs):
+        p = str(tmp_path / ('%d.png' % i))
+        Image.fromarray(a).save(p, compress_level=[1, 6, 9][i % 3], optimize=bool(i & 1))
+        paths.append(p)
+    seen = set()
+    for p in paths:                                                    # which row filters did the encoder choose?
+        import zlib
+        raw = open(p, 'rb').read()
+        pos, idat = 8, b''
+        while pos < len(raw):
+            ln = int.from_bytes(raw[pos:pos + 4], 'big')
+            if raw[pos + 4:pos + 8] == b'IDAT':
+                idat += raw[pos + 8:pos + 8 + ln]
+            pos += 12 + ln
+        rows = zlib.decompress(idat)
+        seen.update(rows[r * 753] for r in range(480))
+    assert len(seen) >= 4, seen                                         # None, Sub, Up, Average / Paeth all occur
+    out = np.zeros((len(paths), 480, 752), np.uint8)
+    decode_batch(paths, out, threads=8)
+    for a, o, p in zip(imgs, out, paths):
+        assert np.array_equal(o, a) and np.array_equal(o, read_image(p))
+    # a hole in the path list leaves its slot alone
+    out2 = np.full((3, 480, 752), 7, np.uint8)
+    decode_batch([paths[0], None, paths[2]], out2, threads=2)
+    assert np.array_equal(out2[0], imgs[0]) and (out2[1] == 7).all() and np.array_equal(out2[2], imgs[2])
+
+
+def test_png_decoder_other_flavours_and_errors(tmp_path):
+    rng = np.random.default_rng(4)
+    g = rng.integers(0, 256, (480, 752), dtype=np.uint8)
+    rgb = str(tmp_path / 'rgb.png'); Image.fromarray(np.stack([g, g, g], -1)).save(rgb)
+    ok = str(tmp_path / 'ok.png'); Image.fromarray(g).save(ok)
+    out = np.zeros((2, 480, 752), np.uint8)
+    decode_batch([rgb, ok], out)                                        # the RGB file goes through Pillow, the other natively
+    assert np.array_equal(out[0], g) and np.array_equal(out[1], g)
+    bad = str(tmp_path / 'bad.png')
+    open(bad, 'wb').write(open(ok, 'rb').read()[:5000])
+    with pytest.raises(N.AirvisionError, match='corrupt|truncated'):
+        decode_batch([ok, bad], out)
+    with pytest.raises(N.AirvisionError, match='cannot open'):
+        decode_batch([str(tmp_path / 'missing.png'), ok], out)
+    small = str(tmp_path / 'small.png'); Image.fromarray(g[:100, :100]).save(small)
+    with pytest.raises(Exception):
+        decode_batch([small, ok], out)                                  # wrong size: Pillow's result does not fit the slot
+
+
+def test_frame_stager_steps_ragged_streams_in_order(tmp_path, cfg):
+    from uav_airvision_amd.euroc import write_euroc_layout
+    from uav_airvision_amd.synth import SyntheticStream
+    roots = []
+    for i, n in enumerate((5, 3)):
+        st = SyntheticStream(cfg, seed=40 + i, n_frames=n, t0=1403636580.0 + 100 * i)
+        roots.append(write_euroc_layout(str(tmp_path / ('S%d' % i)), st))
+    dss = [EuRoCDataset(r) for r in roots]
+    ref = [list(d.stereo) for d in dss]
+    stg = FrameStager(dss, 480, 752, threads=4)
+    k = 0
+    while True:
+        nxt = stg.next()
+        if nxt is None:
+            break
+        ts, i0, i1 = nxt
+        for s in range(2):
+            if k < len(ref[s]):
+                assert ts[s] == ref[s][k].timestamp
+                assert np.array_equal(i0[s], ref[s][k].cam0_image) and np.array_equal(i1[s], ref[s][k].cam1_image)
+            else:
+                assert ts[s] == -1.0 and not i0[s].any() and not i1[s].any()
+        k += 1
+    assert k == 5
+    stg.close()
+    stg = FrameStager(dss, 480, 752, max_frames=2)
+    assert stg.next() is not None and stg.next() is not None and stg.next() is None
+    stg.close()

@@ -92,6 +92,7 @@ SIGNATURES = {
     'av_msckf_batch_get_cov': (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     'av_msckf_batch_sizes': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32 * 3)]),
     'av_msckf_batch_counters': (C.c_int, [_P, C.POINTER(C.c_int64 * 8)]),
+    'av_png_decode_gray8': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int64, C.c_int, _P]),
     'av_quat_to_rotation': (C.c_int, [_P, _P]),
     'av_rotation_to_quat': (C.c_int, [_P, _P]),
     'av_quat_multiply': (C.c_int, [_P, _P, _P]),

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libairvision_hip.so')
-SOURCES = ['ops_api.hip', 'pyramid.hip', 'lk.hip', 'fast.hip', 'frontend.hip', 'msckf.hip']
+SOURCES = ['ops_api.hip', 'pyramid.hip', 'lk.hip', 'fast.hip', 'frontend.hip', 'msckf.hip', 'png_read.hip']
 HEADERS = ['av_common.h', 'msckf_batch.inc', os.path.join('..', '..', 'include', 'airvision.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
          '-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt', '-fno-fast-math', '-fopenmp',
@@ -51,7 +51,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError('hipcc failed for: ' + ', '.join(failed))
     if force or procs or _stale(OUT, objs):
-        cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-fopenmp', '-Wl,-rpath,/opt/rocm/lib/llvm/lib', '-o', OUT] + objs
+        cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-fopenmp', '-Wl,-rpath,/opt/rocm/lib/llvm/lib', '-o', OUT] + objs + ['-lz']
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)

@@ -304,7 +304,7 @@ class MSCKF(object):
         batch = FeatureBatch(cams, zs, self._dev.device)
         row_off, rows, gamma, ok = self._dev.feature_blocks(batch, [f.position for f in feats], dofs, q, p, qn, pn,
                                                             self.T_cam0_cam1, self.gravity, self.config.observation_noise)
-        self.debug.setdefault('gamma', []).extend(gamma.tolist())
+        self._gamma = gamma            # debug['gamma'] gets the ones the reference would have evaluated (see the callers)
         return row_off, rows, ok
 
     def measurement_update(self, blk_rows, blk_lens):
@@ -350,13 +350,16 @@ class MSCKF(object):
             return
         cam_lists = [list(f.observations.keys()) for f in processed]
         row_off, rows, passed = self._blocks(processed, cam_lists, [len(c) - 1 for c in cam_lists])
-        blk_r, blk_l, stacked = [], [], 0
+        blk_r, blk_l, stacked, n_eval = [], [], 0, 0
         for i in range(len(processed)):
+            n_eval = i + 1
             if passed[i]:
                 blk_r.append(row_off[i]); blk_l.append(rows[i])
                 stacked += int(rows[i])
             if stacked > 1500:                      # the cut happens after adding the crossing block (A.8)
                 break
+        # the batched kernel gated every candidate; the reference never evaluates the ones behind the cut (msckf.py:667-668)
+        self.debug.setdefault('gamma', []).extend(self._gamma[:n_eval].tolist())
         self.measurement_update(blk_r, blk_l)
         for f in processed:
             del self.map_server[f.id]
@@ -409,6 +412,7 @@ class MSCKF(object):
             lists.append(involved[feat.id])
         if feats:
             row_off, rows, passed = self._blocks(feats, lists, [len(c) for c in lists])
+            self.debug.setdefault('gamma', []).extend(self._gamma.tolist())          # no cut on this path (msckf.py:759-763)
             blk_r = [row_off[i] for i in range(len(feats)) if passed[i]]
             blk_l = [rows[i] for i in range(len(feats)) if passed[i]]
             for feat, inv in zip(feats, lists):

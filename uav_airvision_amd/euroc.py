@@ -88,10 +88,94 @@ class EuRoCDataset(object):
             i0, i1 = read_image(p0[k]), read_image(p1[k])
             yield stereo_msg(t0[k], i0, i1, img_msg(t0[k], i0), img_msg(t0[k], i1))
 
+    @property
+    def stereo_files(self):
+        """(timestamp, cam0 path, cam1 path) of every frame from the start time on -- what `stereo` decodes; the batch
+        stager (`FrameStager`) decodes these on host threads one step ahead instead."""
+        (p0, t0), (p1, _t1) = self._cam
+        for k in range(min(len(p0), len(p1))):
+            if t0[k] >= self.starttime:
+                yield t0[k], p0[k], p1[k]
+
     def groundtruth_array(self):
         """float64[n, 8]: t, p(3), q as stored by EuRoC (w, x, y, z)."""
         g = self._gt[self._gt[:, 0] >= self.starttime]
         return g[:, :8].copy()
+
+
+def decode_batch(paths, out, threads=16):
+    """Decode len(paths) greyscale PNG files into out[i] (uint8 [n, h, w], C-contiguous) on `threads` host threads with the
+    library's decoder (av_png_decode_gray8: zlib + PNG row filters in C++, no GIL); a file of another PNG flavour (16-bit,
+    RGB, palette ...) is decoded by Pillow.  paths[i] = None leaves out[i] untouched."""
+    import ctypes as C
+    from . import _native as N
+    idx = [i for i, p in enumerate(paths) if p is not None]
+    if not idx:
+        return
+    n, h, w = out.shape
+    assert out.flags['C_CONTIGUOUS'] and out.dtype == np.uint8
+    arr = (C.c_char_p * len(idx))(*[os.fsencode(paths[i]) for i in idx])
+    status = (C.c_int32 * len(idx))()
+    if len(idx) == n:
+        dst, tmp = out, None
+    else:
+        tmp = np.empty((len(idx), h, w), np.uint8); dst = tmp
+    rc = N.lib().av_png_decode_gray8(arr, len(idx), w, h, dst.ctypes.data_as(C.c_void_p), h * w, int(threads), status)
+    if rc == N.AV_E_CAPACITY:                 # some file is not 8-bit greyscale: that file alone goes through Pillow
+        for k, i in enumerate(idx):
+            if status[k] == 1:
+                dst[k] = read_image(paths[i])
+            elif status[k] != 0:
+                N.check(N.AV_E_INVALID)
+    else:
+        N.check(rc)
+    if tmp is not None:
+        out[idx] = tmp
+
+
+class FrameStager(object):
+    """Batch staging for sweeps (reference: the reader threads of streaming/dataset.py:93-158): the frames of
+    step k+1 of all S streams are decoded on host threads while step k runs on the GPU.  `next()` returns
+    (timestamps float64[S] (-1 = stream finished), img0 uint8[S,h,w], img1) of the next step, or None when every stream
+    is done; the arrays stay valid until the call after the next one (two buffers)."""
+
+    def __init__(self, datasets, height, width, max_frames=None, threads=16):
+        from concurrent.futures import ThreadPoolExecutor
+        self.S = len(datasets)
+        self.its = [iter(d.stereo_files) for d in datasets]
+        self.buf = [np.zeros((2, self.S, height, width), np.uint8) for _ in range(2)]      # [slot][camera][stream]
+        self.max_frames, self.threads, self.k = max_frames, threads, 0
+        self.pool = ThreadPoolExecutor(1)
+        self.fut = self.pool.submit(self._load, 0)
+
+    def _load(self, k):
+        if self.max_frames is not None and k >= self.max_frames:
+            return None
+        ent = [next(it, None) for it in self.its]
+        if all(e is None for e in ent):
+            return None
+        ts = np.array([-1.0 if e is None else e[0] for e in ent])
+        buf = self.buf[k & 1]
+        both = [None if e is None else e[1] for e in ent] + [None if e is None else e[2] for e in ent]
+        decode_batch(both, buf.reshape(2 * self.S, buf.shape[2], buf.shape[3]), self.threads)     # cam0 and cam1 of all streams in one threaded call
+        for s, e in enumerate(ent):
+            if e is None:
+                buf[:, s] = 0                    # a finished stream idles on blank images
+        return ts, buf[0], buf[1]
+
+    def next(self):
+        res = self.fut.result()
+        self.k += 1
+        self.fut = self.pool.submit(self._load, self.k) if res is not None else None
+        return res
+
+    def close(self):
+        if self.fut is not None:
+            try:
+                self.fut.result()
+            except Exception:
+                pass
+        self.pool.shutdown(wait=True)
 
 
 def replay(dataset, imu_sinks, on_stereo, max_frames=None):
@@ -112,14 +196,14 @@ def replay(dataset, imu_sinks, on_stereo, max_frames=None):
     return n
 
 
-def write_euroc_layout(root, stream, groundtruth_rate_hz=200.0, frame_range=None, write_csv=True):
+def write_euroc_layout(root, stream, groundtruth_rate_hz=200.0, frame_range=None, write_csv=True, compress_level=6):
     """Write a seeded synthetic stream (uav_airvision_amd.synth.SyntheticStream) as an EuRoC-layout directory
     `root/mav0/{cam0,cam1}/data/<ns>.png`, `imu0/data.csv`, `state_groundtruth_estimate0/data.csv`, so that the same
     reader / replay / sweep code that runs on the real dataset (which is not redistributable and not present on the build
     or GPU boxes) can be exercised end to end.  PNG is lossless: the reader returns the rendered pixels bit for bit.
     Ground truth = the analytic trajectory of the stream (position of the IMU frame; identity orientation columns).
     `frame_range=(a, b)` writes only the images of frames a..b-1 (several writer processes can share one sequence);
-    `write_csv=False` skips the IMU / ground-truth files."""
+    `write_csv=False` skips the IMU / ground-truth files; `compress_level` is zlib's (any level is lossless; 1 writes 5x faster)."""
     from PIL import Image
     for cam in ('cam0', 'cam1'):
         os.makedirs(os.path.join(root, 'mav0', cam, 'data'), exist_ok=True)
@@ -127,8 +211,8 @@ def write_euroc_layout(root, stream, groundtruth_rate_hz=200.0, frame_range=None
     for k in range(a, b):
         m = stream.frame(k)
         name = '%d.png' % int(round(m.timestamp * 1e9))
-        Image.fromarray(m.cam0_image).save(os.path.join(root, 'mav0', 'cam0', 'data', name))
-        Image.fromarray(m.cam1_image).save(os.path.join(root, 'mav0', 'cam1', 'data', name))
+        Image.fromarray(m.cam0_image).save(os.path.join(root, 'mav0', 'cam0', 'data', name), compress_level=compress_level)
+        Image.fromarray(m.cam1_image).save(os.path.join(root, 'mav0', 'cam1', 'data', name), compress_level=compress_level)
     if not write_csv:
         return root
     os.makedirs(os.path.join(root, 'mav0', 'imu0'), exist_ok=True)

@@ -69,11 +69,24 @@ class BatchedRunner(object):
     def close(self):
         self.eng.close(); self.flt.close()
 
-    def run(self, datasets, max_frames=None, on_step=None):
+    def run(self, datasets, max_frames=None, on_step=None, host_threads=16):
+        from .euroc import FrameStager
+        staged = all(hasattr(d, 'stereo_files') for d in datasets)
+        stager = FrameStager(datasets, self.eng.height, self.eng.width, max_frames=max_frames, threads=host_threads) if staged else None
+        try:
+            return self._run(datasets, stager, max_frames, on_step)
+        finally:
+            if stager is not None:
+                stager.close()
+
+    def _run(self, datasets, stager, max_frames, on_step):
         S = self.S
         assert len(datasets) == S
         eng, flt = self.eng, self.flt
-        its_img = [iter(d.stereo) for d in datasets]
+        staged = stager is not None
+        # frames: decoded one step ahead on host threads when the datasets list their files (euroc.FrameStager; reference:
+        # the reader threads of streaming/dataset.py:93-158); any other dataset-shaped object is read through `.stereo`
+        its_img = None if staged else [iter(d.stereo) for d in datasets]
         its_imu = [iter(d.imu) for d in datasets]
         pend = [next(it, None) for it in its_imu]
         img0 = np.zeros((S, eng.height, eng.width), np.uint8)
@@ -89,23 +102,34 @@ class BatchedRunner(object):
 
         step = 0
         while True:
-            msgs = [next(it, None) for it in its_img] if (max_frames is None or step < max_frames) else [None] * S
-            if all(m is None for m in msgs):
-                break
+            if staged:
+                nxt = stager.next()
+                if nxt is None:
+                    break
+                frame_ts, img0, img1 = nxt
+            else:
+                msgs = [next(it, None) for it in its_img] if (max_frames is None or step < max_frames) else [None] * S
+                if all(m is None for m in msgs):
+                    break
+                frame_ts = np.array([-1.0 if m is None else m.timestamp for m in msgs])
+                for s, m in enumerate(msgs):
+                    if m is None:
+                        its_img[s] = iter(())
+                        img0[s] = 0; img1[s] = 0
+                    else:
+                        img0[s] = m.cam0_image; img1[s] = m.cam1_image
             ts_f = np.full(S, -1.0)                       # the filter's frame times: < 0 = no frame for this stream
             ts_e = np.empty(S)
             idx, tt, gy, ac = [], [], [], []
-            for s, m in enumerate(msgs):
-                if m is None:                             # finished: idles on blank images until the longest stream ends
-                    its_img[s] = iter(())
-                    img0[s] = 0; img1[s] = 0
+            for s in range(S):
+                if frame_ts[s] < 0:                       # finished: idles on blank images until the longest stream ends
                     last_t[s] += 0.05
                     ts_e[s] = last_t[s]
                     continue
-                ts_f[s] = ts_e[s] = last_t[s] = m.timestamp
-                img0[s] = m.cam0_image; img1[s] = m.cam1_image
+                t = float(frame_ts[s])
+                ts_f[s] = ts_e[s] = last_t[s] = t
                 self.frames_done[s] += 1
-                while pend[s] is not None and pend[s].timestamp <= m.timestamp:      # SURVEY 3.5 / vio.py:43-44
+                while pend[s] is not None and pend[s].timestamp <= t:      # SURVEY 3.5 / vio.py:43-44
                     idx.append(s); tt.append(pend[s].timestamp); gy.append(pend[s].angular_velocity); ac.append(pend[s].linear_acceleration)
                     pend[s] = next(its_imu[s], None)
             if idx:
