@@ -33,18 +33,32 @@ sys.path.insert(0, ROOT)
 W_IMG, H_IMG = 752, 480
 LK_BYTES_PER_POINT_PASS = 4 * 2 * 289 + 25          # L=4 levels x (I + J window of 17x17) + point I/O
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/s spec
-# rocprofv3 PMC passes of `bench.py --frontend-only --streams 64` (profiles/r02/pmc_frontend_s64_summary.json, collected by
-# profiles/r02/collect_pmc.sh: SQ block, FETCH_SIZE and WRITE_SIZE in three separate passes), mean per lk_track_g16_kernel
-# launch over the launch mix of a step (temporal, stereo forward / backward of the tracked points: 300 point passes per stream
-# each; candidates round 1 forward / backward: 100 each; round 2: ~11 each), 64 streams per launch:
-#   FETCH_SIZE 37,720.6 KB, WRITE_SIZE 169.0 KB (memory side of L2), SQ_INSTS_VALU 21,366,779 wave-instructions.
-# bench.py's avg_launch_ms is the mean over the same mix, so per-launch means scale by streams / 64.
-# Traffic is corrected as MI355X_MICROARCH.md "HBM" prescribes for gfx950 (FETCH_SIZE x 2; WRITE_SIZE exact).  The x2 rule is
-# calibrated for 16-B/lane streams; this kernel stages its tiles with 4-byte lane loads, and the RAW figure is already about
-# the bytes of the pyramid regions a launch touches: read the corrected value as an upper bound.
-LK_PMC_STREAMS = 64
-LK_TRAFFIC_BYTES_PER_LAUNCH_S64 = (2 * 37720.6 + 169.0) * 1024
-LK_VALU_INSTS_PER_LAUNCH_S64 = 21366779.0
+# rocprofv3 PMC passes of `bench.py --frontend-only --streams 64` (three separate passes: SQ block, FETCH_SIZE, WRITE_SIZE; collected
+# by profiles/r03/collect_pmc.sh, per-kernel means in the committed summary read below).  Per lk_track_g16_kernel launch, mean over
+# the launch mix of a step (temporal, stereo forward / backward of the tracked points: 300 point passes per stream each; candidates
+# round 1 forward / backward: 100 each; round 2: ~10 each), 64 streams per launch; bench.py's avg_launch_ms is the mean over the same
+# mix, so per-launch means scale by streams / 64.
+# FETCH_SIZE correction: MI355X_MICROARCH.md prescribes x2 on gfx950 for 16-byte-per-lane streams and asks for a calibration of
+# other access patterns.  profiles/r03/fetch_calib.{hip,json} (run on the GPU box under the same --pmc pass) reads KNOWN byte counts
+# with 16-, 4- and 1-byte lane loads and with one dword per 128-byte / per 64-byte line: FETCH_SIZE reports 0.50000 of the bytes in
+# every case, and a sparse read costs the time of the whole line (a request is 128 B, tallied as 64) -- so the x2 applies to this
+# kernel's 4-byte staging loads as well (round 2 argued it might not; it does).  WRITE_SIZE is exact.
+def _load_pmc():
+    for d in ('r03', 'r02'):
+        path = os.path.join(ROOT, 'profiles', d, 'pmc_frontend_s64_summary.json')
+        if os.path.exists(path):
+            e = json.load(open(path))['lk_track_g16_kernel<15>']
+            return dict(path=os.path.relpath(path, ROOT), streams=64, fetch_kb=float(e['FETCH_SIZE']), write_kb=float(e['WRITE_SIZE']),
+                        valu=float(e['SQ_INSTS_VALU']), waves=float(e['SQ_WAVES']))
+    raise RuntimeError('bench.py: no committed PMC summary under profiles/')
+
+
+FETCH_SIZE_FACTOR = 2.0                             # measured: profiles/r03/fetch_calib.json (raw_over_known = 0.5 for every lane width)
+LK_PMC = _load_pmc()
+LK_PMC_STREAMS = LK_PMC['streams']
+LK_TRAFFIC_BYTES_PER_LAUNCH_S64 = (FETCH_SIZE_FACTOR * LK_PMC['fetch_kb'] + LK_PMC['write_kb']) * 1024
+LK_VALU_INSTS_PER_LAUNCH_S64 = LK_PMC['valu']
+FP64_PEAK_TFLOPS = 78.6                             # MI355X_MICROARCH.md: fp64 vector = fp64 matrix peak
 VALU_CYCLES_PER_WAVE_INST = 2.0                     # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
 
@@ -61,9 +75,9 @@ def frame_bytes(n_t, n_trk, n_cand):
     return 2 * W_IMG * H_IMG + 2 * 118440 + p * LK_BYTES_PER_POINT_PASS, p
 
 
-def make_config():
+def make_config(grid=(4, 5, 15)):
     from uav_airvision_amd.config import ConfigEuRoC
-    return ConfigEuRoC(grid_row=4, grid_col=5, grid_min_feature_num=3, grid_max_feature_num=15)
+    return ConfigEuRoC(grid_row=grid[0], grid_col=grid[1], grid_min_feature_num=3, grid_max_feature_num=grid[2])
 
 
 def cpu_baseline(cfg, with_msckf, budget_s=10.0, max_frames=400, seed=0, traj_frames=0):
@@ -120,7 +134,7 @@ def cpu_baseline(cfg, with_msckf, budget_s=10.0, max_frames=400, seed=0, traj_fr
     return out
 
 
-def cpu_baseline_all_cores(with_msckf, budget_s=6.0):
+def cpu_baseline_all_cores(with_msckf, budget_s=6.0, grid=(4, 5, 15)):
     """The same single-thread port, one independent stream per host core in parallel child processes (they never touch the
     GPU): the CPU box's aggregate rate on this workload, for context next to the one-core figure."""
     import subprocess
@@ -129,7 +143,7 @@ def cpu_baseline_all_cores(with_msckf, budget_s=6.0):
     except Exception:
         n = os.cpu_count() or 1
     n = max(1, min(16, n))                     # a GPU box gives one GPU's job a share of 16 cores
-    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--cpu-budget', str(budget_s)]
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--cpu-budget', str(budget_s), '--grid'] + [str(v) for v in grid]
     if not with_msckf:
         cmd.append('--frontend-only')
     procs = [subprocess.Popen(cmd + ['--cpu-seed', str(100 + i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(n)]
@@ -221,7 +235,9 @@ def main():
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--streams', type=int, default=2048, help='independent stereo streams per GPU')
-    ap.add_argument('--unique', type=int, default=4, help='distinct rendered streams (replicated with per-stream noise)')
+    ap.add_argument('--unique', type=int, default=64, help='distinct rendered streams (own scene, own speed and phase of the trajectory); replicated with per-stream noise')
+    ap.add_argument('--grid', nargs=3, type=int, default=[4, 5, 15], metavar=('ROWS', 'COLS', 'MAX'),
+                    help='feature grid: 4 5 15 = 300 features/frame (BASELINE configs[1], the default); 10 15 10 = 1500 (configs[4])')
     ap.add_argument('--no-stagger', action='store_true', help='start every replica at frame 0 (all filters then prune on the same frames)')
     ap.add_argument('--host-images', action='store_true', help='front-end only, images handed over as host numpy arrays every step '
                     '(av_frontend_step_host: the PCIe-inclusive rate quoted in DESIGN.md; never the contract value)')
@@ -233,7 +249,7 @@ def main():
     ap.add_argument('--frontend-only', action='store_true', help='time only the image front-end (BASELINE configs[1] literally: MSCKF not on the GPU)')
     args = ap.parse_args()
     if args.cpu_baseline_worker:               # child of cpu_baseline_all_cores: CPU only, exits before torch is imported
-        print(json.dumps(cpu_baseline(make_config(), not args.frontend_only, budget_s=args.cpu_budget, seed=args.cpu_seed)))
+        print(json.dumps(cpu_baseline(make_config(args.grid), not args.frontend_only, budget_s=args.cpu_budget, seed=args.cpu_seed)))
         return 0
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         return self_launch(args.gpus)           # before torch / HIP are touched in this process
@@ -261,7 +277,8 @@ def main():
     if world > 1 and 'AV_HOST_THREADS' not in os.environ:
         # the filter's bookkeeping threads of all ranks share the node's cores: keep every rank inside its share
         os.environ['AV_HOST_THREADS'] = str(max(4, min(16, (os.cpu_count() or 16) // world)))
-    cfg = make_config()
+    cfg = make_config(args.grid)
+    n_grid_feat = args.grid[0] * args.grid[1] * args.grid[2]
     S, K, Wm = args.streams, args.steps, args.warmup
     with_msckf = not (args.frontend_only or args.host_images)
     PRE = PREROLL_FULL if with_msckf else PREROLL_FE
@@ -279,20 +296,40 @@ def main():
     U = max(1, min(args.unique, S))
     t_gen = time.time()
     stream_seed0 = base_seed + 97 * rank
-    streams = [SyntheticStream(cfg, seed=stream_seed0 + u, n_frames=F) for u in range(U)]
-    base0 = np.empty((U, F, H_IMG, W_IMG), np.uint8)
-    base1 = np.empty((U, F, H_IMG, W_IMG), np.uint8)
-    for u, st in enumerate(streams):
-        for k in range(F):
-            m = st.frame(k)
-            base0[u, k] = m.cam0_image
-            base1[u, k] = m.cam1_image
+    # U distinct streams.  Stream 0 is exactly SyntheticStream(seed) rendered by numpy (the CPU path replays it for `ate_vs_cpu_ref`);
+    # the others are rendered on the GPU by the same renderer restated in torch, each with its own scene (its own texture up to 8,
+    # then a random window of one of the 8), its own speed (motion_scale 0.7-1.6) and its own phase (0-2 s of standstill before the
+    # trajectory starts), so that LK iteration counts, track loss and the filter's work per frame differ between streams instead of
+    # marching in lock-step.
+    from uav_airvision_amd.synth import make_texture
+    prng = np.random.default_rng(base_seed + 7919 * rank)
+    tex_pool = [make_texture(0xA1B0 + stream_seed0 + j) for j in range(min(U, 8))]
+    streams = []
+    for u in range(U):
+        if u == 0:
+            st = SyntheticStream(cfg, seed=stream_seed0, n_frames=F, texture=tex_pool[0])
+        else:
+            st = SyntheticStream(cfg, seed=stream_seed0 + u, n_frames=F, texture=tex_pool[u % len(tex_pool)], render=False,
+                                 motion_scale=float(prng.uniform(0.7, 1.6)), rest=float(prng.uniform(0.0, 2.0)),
+                                 tex_offset=(0.0, 0.0) if u < len(tex_pool) else (float(prng.uniform(0, 2048)), float(prng.uniform(0, 1536))))
+            st.tex, st.rays0, st.rays1 = tex_pool[u % len(tex_pool)], streams[0].rays0, streams[0].rays1
+        streams.append(st)
+    b0 = torch.empty((U, F, H_IMG, W_IMG), dtype=torch.uint8, device=dev)
+    b1 = torch.empty((U, F, H_IMG, W_IMG), dtype=torch.uint8, device=dev)
+    for k in range(F):
+        m = streams[0].frame(k)
+        b0[0, k] = torch.from_numpy(m.cam0_image).to(dev)
+        b1[0, k] = torch.from_numpy(m.cam1_image).to(dev)
     g = torch.Generator(device=dev)
     g.manual_seed(base_seed + rank)
+    rays_dev = (torch.from_numpy(streams[0].rays0).to(dev), torch.from_numpy(streams[0].rays1).to(dev))
+    tex_dev = [torch.from_numpy(t).to(dev) for t in tex_pool]
+    for u in range(1, U):
+        state = dict(tex=tex_dev[u % len(tex_pool)], rays0=rays_dev[0], rays1=rays_dev[1])
+        for k in range(F):
+            b0[u, k], b1[u, k] = streams[u].frame_torch(k, state, g)
     img0 = torch.empty((F, S, H_IMG, W_IMG), dtype=torch.uint8, device=dev)
     img1 = torch.empty((F, S, H_IMG, W_IMG), dtype=torch.uint8, device=dev)
-    b0 = torch.from_numpy(base0).to(dev)
-    b1 = torch.from_numpy(base1).to(dev)
     for s in range(S):
         u = s % U
         for dst, src in ((img0, b0), (img1, b1)):
@@ -301,7 +338,7 @@ def main():
             else:
                 noise = torch.randint(-2, 3, (F, H_IMG, W_IMG), generator=g, device=dev, dtype=torch.int16)
                 dst[:, s] = (src[u].to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
-    del b0, b1
+    del b0, b1, tex_dev, rays_dev
     # IMU samples per step, all streams, as flat arrays for the batched push
     imu_steps = []
     its = [iter(st.imu) for st in streams]
@@ -355,7 +392,7 @@ def main():
     flt = None
     if with_msckf:
         from uav_airvision_amd.msckf_ops import BatchedMSCKF
-        flt = BatchedMSCKF(cfg, S, device=local_rank, rows_cap=4096, max_features=eng.max_features)
+        flt = BatchedMSCKF(cfg, S, device=local_rank, rows_cap=4096 if 5 * eng.max_features + 64 <= 4096 else None, max_features=eng.max_features)
     msckf_s = [0.0]
     push_s = [0.0]
     poses0 = []                                  # (frame index, out[S,12]) of every filter step: stream 0's row is the GPU trajectory
@@ -464,6 +501,7 @@ def main():
             run(k)
     eng.read_features()
     c_t0 = flt.counters() if flt is not None else None
+    w_t0 = flt.work(enable=1) if flt is not None else None      # HIP events around the filter's phase chains from here on
     eng.enable_timing(16 * (F - PRE - Wm) + 16)
 
     barrier()
@@ -487,6 +525,7 @@ def main():
         tt = [t for k, t in step_times if k >= T0]
         sys.stderr.write('[step intervals ms] ' + ' '.join('%.1f' % ((b_ - a_) * 1e3) for a_, b_ in zip(tt[:-1], tt[1:])) + '\n')
     c_t1 = flt.counters() if flt is not None else None
+    w_t1 = flt.work(enable=0) if flt is not None else None
     fe_elapsed = None
     timing_fe = None
     if with_msckf:                                   # same engine state, next K frames, front-end only
@@ -525,14 +564,15 @@ def main():
             'vs_baseline': None, 'dtype': 'u8/int32 windows, f32 normal equations', 'data': 'synthetic',
             'inputs': 'host numpy arrays, H2D inside the timed region (PCIe-inclusive)' if args.host_images else 'resident in HBM',
             'config': {
-                'workload': ('BASELINE configs[1] shape (synthetic 752x480 stereo streams, grid 4x5x15 = 300 features/frame): temporal LK + '
+                'workload': ('BASELINE configs[%s] shape (synthetic 752x480 stereo streams, grid %dx%dx%d = %d features/frame): temporal LK + '
+                             % ('1' if n_grid_feat <= 300 else '4', args.grid[0], args.grid[1], args.grid[2], n_grid_feat) +
                              'stereo LK fwd/bwd + gates + FAST/grid add/prune/publish on device, ' +
                              ('followed in the same step by the batched HIP MSCKF (propagation, augmentation, triangulation, Jacobians + '
                               'null-space + gate, QR-compressed update, pruning) on the published features'
                               if with_msckf else 'MSCKF not in the step (configs[1] literally)')),
                 'streams_per_gpu': S, 'unique_rendered_streams': U, 'parallelism': 'stream-sharded x%d' % world,
-                'replication': ('%d rendered streams replicated to %d per GPU with +-2 grey levels of per-stream noise; replicas of one rendered '
-                                'stream see near-identical scenes, so their work per step is near-identical' % (U, S)) +
+                'replication': ('%d distinct streams (own scene, trajectory speed 0.7-1.6x, 0-2 s phase; stream 0 = the stream the CPU path replays), '
+                                'replicated to %d per GPU with +-2 grey levels of per-replica noise' % (U, S)) +
                                ('; the filters of the odd replicas start one step later, so half of the filters run the two-camera prune on even and half on odd steps'
                                 if stagger else '; all filters start at step 0, so all of them prune on the same steps (lock-step load)'),
                 'tracked_features_per_frame': n_t, 'published_features_per_frame': n_pub,
@@ -552,8 +592,8 @@ def main():
                 'bound': 'hbm', 'kernel': 'lk_track_g16_kernel<15>',
                 'achieved': lk_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': lk_gbs / HBM_PEAK_GBS,
                 'traffic': LK_TRAFFIC_BYTES_PER_LAUNCH_S64 * S / LK_PMC_STREAMS,
-                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r02/pmc_frontend_s64_summary.json, FETCH x2 per '
-                                  'MI355X_MICROARCH.md; scaled from 64 streams per launch to %d' % S,
+                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), %s, FETCH x%.1f (MI355X_MICROARCH.md; confirmed for 4-byte lane '
+                                  'loads by profiles/r03/fetch_calib.json); scaled from 64 streams per launch to %d' % (LK_PMC['path'], FETCH_SIZE_FACTOR, S),
                 # the kernel is VALU-issue bound: instructions issued / what the chip's 1,024 SIMDs could issue in the launch's duration
                 'valu_issue_frac': ((LK_VALU_INSTS_PER_LAUNCH_S64 * S / LK_PMC_STREAMS) * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * CLOCK_HZ) / (lk_avg_ms * 1e-3)) if lk_avg_ms > 0 else None,
                 'valu_issue_frac_frontend_only': ((LK_VALU_INSTS_PER_LAUNCH_S64 * S / LK_PMC_STREAMS) * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * CLOCK_HZ) /
@@ -568,16 +608,36 @@ def main():
                 'avg_launch_ms_frontend_only': (timing_fe['lk'][0] / max(timing_fe['lk'][1], 1)) if timing_fe else None,
             },
             'kernel_ms_per_step': {k: v[0] / K for k, v in timing.items()},
+            'pmc_constants': dict(LK_PMC, fetch_size_factor=FETCH_SIZE_FACTOR, fetch_calibration='profiles/r03/fetch_calib.json'),
             'data_gen_s': gen_s,
             'msckf_in_step': with_msckf, 'msckf_wall_ms_per_step': 1e3 * msckf_s[0] / K, 'msckf_push_imu_ms_per_step': 1e3 * push_s[0] / K,
             'frontend_only_frames_per_s': (world * S * K / fe_elapsed) if fe_elapsed else None,
         }
+        if w_t0 is not None:
+            dw = {k: w_t1[k] - w_t0[k] for k in w_t1}
+            fl = dw['gate_flops'] + dw['update_flops']
+            tf = fl / (dw['chain_ms'] * 1e-3) / 1e12 if dw['chain_ms'] > 0 else 0.0
+            out['roofline_msckf'] = {
+                'bound': 'fp64 vector FMA (= fp64 MFMA peak on MI355X); the stage itself is latency / LDS bound (SURVEY 8d)',
+                'kernels': 'triangulate, feature_kernel<16|64|256>, upd_stack, upd_info, update_front_batch, upd_gather/tt/s/chol/fsolve/p',
+                'achieved': tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / FP64_PEAK_TFLOPS,
+                'algorithmic_flops_per_step': fl / K, 'gate_flops_per_step': dw['gate_flops'] / K, 'update_flops_per_step': dw['update_flops'] / K,
+                'reference_qr_flops_per_step_not_counted': dw['reference_qr_flops'] / K,
+                'features_gated_per_stream_step': dw['features_gated'] / K / S, 'rows_stacked_per_update': dw['rows_stacked'] / max(dw['updates'], 1.0),
+                'updates_per_stream_step': dw['updates'] / K / S,
+                'chain_ms_per_step': dw['chain_ms'] / K,
+                'how': 'flops: SURVEY 8(d) formulas on the sizes actually processed (gate: r = 4M-3 rows x n; update: k = min(m, n) rows kept), '
+                       'the reference-size thin QR (2mn^2 - 2/3 n^3, msckf.py:554) listed apart because the column-compressed update never runs it; '
+                       'time: HIP events on every stream group\'s stream around the launches of each phase (triangulation .. covariance update), '
+                       'summed over the %d groups, inside the timed region of the complete path (so it includes waiting for CUs the front-end holds)'
+                       % len(os.environ.get('AV_MSCKF_GROUPS', '4')),
+            }
         if world == 1 and not args.no_cpu_baseline:
             n_traj = (T0 + K) if with_msckf else 0
             cb = cpu_baseline(cfg, with_msckf, seed=stream_seed0, max_frames=max(400, n_traj), traj_frames=n_traj)
             cpu_traj, truth = cb.pop('_traj', None), cb.pop('_truth', None)
             out['cpu_baseline'] = cb
-            out['cpu_baseline_all_cores'] = cpu_baseline_all_cores(with_msckf)
+            out['cpu_baseline_all_cores'] = cpu_baseline_all_cores(with_msckf, grid=args.grid)
             if with_msckf and cpu_traj:
                 from uav_airvision_amd.evaluate import ate
                 gpu_traj = np.array([[frame_ts[k][0]] + [float(v) for v in o[0, 2:9]] for k, o in sorted(poses0, key=lambda e: e[0]) if o[0, 0] > 0.5])

@@ -315,6 +315,14 @@ int  av_msckf_batch_stream_status(av_msckf_batch* b, int stream_idx, int32_t* st
  * reallocations after the first step (0 in a correctly pre-sized run), min camera states, max camera states,
  * min map features, max map features].  bench.py uses it to prove that the timed region is the steady state. */
 int  av_msckf_batch_counters(av_msckf_batch* b, int64_t out8[8]);
+/* Work done so far, for the filter stage's roofline (drain first): out8 = [algorithmic fp64 flops of the gating tests
+ * (per feature with r = 4M-3 rows, n columns: 2rn^2 + 2r^2n + r^3/3; msckf.py:604-612), of the measurement updates on the
+ * k = min(m, n) rows kept (S 2kn^2 + 2k^2n, Cholesky k^3/3, solve 2k^2n, (I-KH)P 4kn^2; msckf.py:562-602), of the reference's
+ * thin QR by the survey's formula (2mn^2 - 2/3 n^3 when m > n, msckf.py:554-557 -- reported apart: the column-compressed update
+ * never runs a QR of that size), features gated, updates run, rows stacked, milliseconds the phase chains (triangulation ..
+ * covariance update) spent on the device summed over stream groups, 0].  The time needs enable = 1 on an earlier call (two HIP
+ * events per phase and group); enable = 0 switches it off, enable < 0 only reads. */
+int  av_msckf_batch_work(av_msckf_batch* b, int enable, double out8[8]);
 
 /* Measurement hooks (bench.py's roofline leg; no reference counterpart): when enabled, every
  * launch group of av_frontend_step is bracketed by a HIP event pair ON THE STEP'S STREAM.

@@ -2117,7 +2117,7 @@ struct StackArgs {
     const int* row_off;              // [n_feat] first row of every feature's block
     int* blk_row; int* blk_len;      // out: stacked blocks of stream s at [rbeg[s], rbeg[s] + n_blk)
     int* cols; int cols_stride;      // out: touched state columns of stream s at cols + s * cols_stride (ascending)
-    const UpdArgs* base;             // [S] per-stream constants (pointers, n, ld, ...); base.mode = 1: information form allowed
+    const UpdArgs* base;             // [S] per-stream constants (pointers, n, ld, ...); base.mode = 1: information form allowed, 2: no update
     UpdArgs* out;                    // [rounds][S]
     int S, rounds, cut1500, kch;
     int compress;                    // 1: a stream with more than kch rows is QR-compressed (update_front_batch_kernel) and updated in ONE round
@@ -2164,7 +2164,8 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
     overflow = __ballot(overflow) != 0ull;
     const UpdArgs b = a.base[s];
     const int nc = 6 * __popcll(used);
-    const int m = overflow ? 0 : stacked;
+    const bool dead = b.mode == 2;                      // stopped by the host (msckf_batch.inc: b_fail_stream): no update, stacked = -1
+    const int m = (overflow || dead) ? 0 : stacked;
     // (the information form holds for any m >= 1; a stream the host marked for it never needs a Cholesky round)
     const int mode = (m > 0 && b.mode == 1 && nc <= INFO_NC && m <= INFO_MAXROWS) ? 1 : 0;
     __syncthreads();
@@ -2188,7 +2189,7 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
     __syncthreads();
     const int nch = s_nch;
     const bool too_many = nch > a.rounds || nch > 62;
-    if (lane == 0) a.stacked[s] = overflow || too_many ? -1 : m;
+    if (lane == 0) a.stacked[s] = overflow || too_many || dead ? -1 : m;
     for (int r = lane; r < a.rounds; r += 64) {
         UpdArgs u = b;
         u.mode = mode; u.round = r; u.kdir = 0; u.nc = nc; u.cols = a.cols + (size_t)s * a.cols_stride;

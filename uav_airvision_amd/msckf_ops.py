@@ -282,3 +282,13 @@ class BatchedMSCKF(object):
         msg = C.create_string_buffer(160)
         N.check(N.lib().av_msckf_batch_stream_status(self._h, int(s), C.byref(st), msg, 160))
         return int(st.value), msg.value.decode()
+
+    WORK_NAMES = ('gate_flops', 'update_flops', 'reference_qr_flops', 'features_gated', 'updates', 'rows_stacked', 'chain_ms')
+
+    def work(self, enable=-1):
+        """Algorithmic fp64 flops of the gates / updates run so far and the device time of the phase chains
+        (av_msckf_batch_work); enable=1/0 switches the event timing on / off, -1 only reads.  Drains the queue first."""
+        self.wait(0)
+        o = (C.c_double * 8)()
+        N.check(N.lib().av_msckf_batch_work(self._h, int(enable), C.byref(o)))
+        return dict(zip(self.WORK_NAMES, [float(v) for v in o]))

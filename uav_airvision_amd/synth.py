@@ -88,7 +88,7 @@ class SyntheticStream(object):
     """
 
     def __init__(self, config, seed=0, n_frames=20, t0=100.0, lead_in=1.0, motion_scale=1.0,
-                 pixel_noise=1.0, texture=None, render=True, rest=0.0):
+                 pixel_noise=1.0, texture=None, render=True, rest=0.0, tex_offset=(0.0, 0.0)):
         self.config = config
         self.seed = int(seed)
         self.n_frames = int(n_frames)
@@ -96,6 +96,7 @@ class SyntheticStream(object):
         self.lead_in = float(lead_in)
         self.rest = float(rest)                 # seconds of standstill after frame 0 (EuRoC sequences start at rest on the ground)
         self.motion_scale = float(motion_scale)
+        self.tex_offset = (float(tex_offset[0]), float(tex_offset[1]))      # texels: which part of the (wrapping) texture the wall shows
         self.pixel_noise = float(pixel_noise)
         self.rng = np.random.default_rng(0xA1B0 + self.seed)
         self.tex = (make_texture(0xA1B0 + self.seed) if texture is None else texture) if render else None
@@ -156,8 +157,8 @@ class SyntheticStream(object):
         r = rays @ R_c_w.T                                        # ray directions in world
         s = (self.wall_d - self.wall_n @ c_w) / (r @ self.wall_n)
         X = c_w + r * s[..., None]
-        u = (X @ self.wall_e1) * TEX_SCALE + self.tex.shape[1] / 2
-        v = (X @ self.wall_e2) * TEX_SCALE + self.tex.shape[0] / 2
+        u = (X @ self.wall_e1) * TEX_SCALE + self.tex.shape[1] / 2 + self.tex_offset[0]
+        v = (X @ self.wall_e2) * TEX_SCALE + self.tex.shape[0] / 2 + self.tex_offset[1]
         th, tw = self.tex.shape
         u0 = np.floor(u); v0 = np.floor(v)
         fu = (u - u0).astype(np.float32); fv = (v - v0).astype(np.float32)
@@ -189,6 +190,44 @@ class SyntheticStream(object):
     def frames(self):
         for k in range(self.n_frames):
             yield self.frame(k)
+
+    # ---- the same renderer in torch (bench data generation: many distinct streams rendered on the GPU) ----------
+    def torch_state(self, device):
+        """Device copies of what `frame_torch` needs (texture, per-pixel rays); build once per stream (textures may be shared)."""
+        import torch
+        return dict(tex=torch.from_numpy(self.tex).to(device), rays0=torch.from_numpy(self.rays0).to(device),
+                    rays1=torch.from_numpy(self.rays1).to(device))
+
+    def frame_torch(self, k, state, generator=None):
+        """(cam0, cam1) uint8 tensors of frame k: `_render` restated with torch ops (fp64 geometry, fp32 bilinear lookup).  The
+        sensor noise comes from torch's generator, not numpy's, so the pixels are NOT those of `frame(k)`: same scene, same
+        statistics.  Streams that must equal the CPU path's input are rendered with `frame`."""
+        import torch
+        t = self.frame_time(k)
+        R_i_w, p = self.R_i_w(t), self.position(t)
+        out = []
+        tex = state['tex']
+        th, tw = tex.shape
+        dev = tex.device
+        for rays, T in ((state['rays0'], self.T_c0_i), (state['rays1'], self.T_c1_i)):
+            R_c_w = torch.from_numpy(np.ascontiguousarray(R_i_w @ T[:3, :3])).to(dev)
+            c_w = torch.from_numpy(p + R_i_w @ T[:3, 3]).to(dev)
+            n = torch.from_numpy(self.wall_n).to(dev)
+            e1 = torch.from_numpy(self.wall_e1).to(dev); e2 = torch.from_numpy(self.wall_e2).to(dev)
+            r = rays @ R_c_w.T
+            s_ = (self.wall_d - torch.dot(n, c_w)) / (r @ n)
+            X = c_w + r * s_[..., None]
+            u = (X @ e1) * TEX_SCALE + tw / 2 + self.tex_offset[0]
+            v = (X @ e2) * TEX_SCALE + th / 2 + self.tex_offset[1]
+            u0 = torch.floor(u); v0 = torch.floor(v)
+            fu = (u - u0).to(torch.float32); fv = (v - v0).to(torch.float32)
+            ui = torch.remainder(u0.to(torch.int64), tw); vi = torch.remainder(v0.to(torch.int64), th)
+            ui1 = torch.remainder(ui + 1, tw); vi1 = torch.remainder(vi + 1, th)
+            img = (tex[vi, ui] * (1 - fu) + tex[vi, ui1] * fu) * (1 - fv) + (tex[vi1, ui] * (1 - fu) + tex[vi1, ui1] * fu) * fv
+            if self.pixel_noise > 0:
+                img = img + torch.randn(img.shape, generator=generator, device=dev, dtype=torch.float32) * self.pixel_noise
+            out.append(torch.clamp(torch.round(img), 0, 255).to(torch.uint8))
+        return out[0], out[1]
 
 
 def replay(stream, imu_sinks, on_frame):
