@@ -388,7 +388,7 @@ def main():
             return 4
         fe_stream = torch.cuda.ExternalStream(hs.value, device=dev)
         torch.cuda.set_stream(fe_stream)
-    eng = FrontendEngine(cfg, n_streams=S, device=local_rank)
+    eng = FrontendEngine(cfg, n_streams=S, device=local_rank, inputs_persist=True)      # every frame of the run is resident in HBM
     flt = None
     if with_msckf:
         from uav_airvision_amd.msckf_ops import BatchedMSCKF

@@ -117,7 +117,7 @@ typedef struct av_frontend_config {
     int32_t lk_levels;                       /* config.pyramid_levels + 1 (config.py:34)            */
     int32_t lk_max_iter;                     /* config.max_iteration (config.py:31)                 */
     int32_t max_corners;                     /* capacity for FAST keypoints of one image            */
-    int32_t reserved0;
+    int32_t flags;                           /* AV_FE_* bits below                                  */
     double  lk_eps;                          /* config.track_precision (config.py:32)               */
     double  lk_min_eig;                      /* OpenCV default minEigThreshold = 1e-4               */
     double  stereo_threshold;                /* config.py:30                                        */
@@ -141,6 +141,14 @@ int av_frontend_push_imu(av_frontend* fe, int stream, double timestamp, const do
 /* n IMU samples in one call: sample i goes to stream stream_idx[i]; gyro is [n][3]. */
 int av_frontend_push_imu_batch(av_frontend* fe, const int32_t* stream_idx, const double* timestamps,
                                const double* gyro, int n);
+
+/* av_frontend_config.flags.  AV_FE_INPUTS_PERSIST: the device images handed to av_frontend_step stay valid and unmodified
+ * until the kernels of the NEXT av_frontend_step of this engine have completed.  The engine then reads pyramid level 0 in place
+ * (LK and FAST index the caller's image, with BORDER_REFLECT_101 arithmetic at the border) and builds only levels 1..3 -- no
+ * padded copy of the 752x480 level: 0.8 MB less HBM traffic per stereo frame.  Without the flag the inputs are only read during
+ * the call's own kernels and level 0 is copied (the round-1/2 behaviour).  av_frontend_step_host always works in place: the
+ * images live in the library's own staging slots.  Results are bit-identical either way. */
+#define AV_FE_INPUTS_PERSIST 1
 
 /* ImageProcessingPipeline.stereo_callback for every stream at once (pipeline.py:46-150).
  * Stream s reads its cam0/cam1 images (tightly packed width*height u8, device memory) at

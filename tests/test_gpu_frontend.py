@@ -22,9 +22,20 @@ def _run_oracle(cfg, stream):
 
 
 def _run_engine(cfg, streams, max_corners=8192):
+    """Both flavours of the engine: level 0 copied into the padded pyramid (inputs only valid during the step) and level 0 read
+    in place from the caller's tensors (AV_FE_INPUTS_PERSIST).  They must agree bit for bit; the caller compares with the oracle."""
+    a = _run_engine_mode(cfg, streams, max_corners, False)
+    b = _run_engine_mode(cfg, streams, max_corners, True)
+    for sa, sb in zip(a, b):
+        for (ia, ua, ca), (ib, ub, cb) in zip(sa, sb):
+            assert np.array_equal(ia, ib) and np.array_equal(ua.view(np.uint64), ub.view(np.uint64)) and ca == cb
+    return b
+
+
+def _run_engine_mode(cfg, streams, max_corners, persist):
     import torch
     from uav_airvision_amd.frontend import FrontendEngine
-    eng = FrontendEngine(cfg, n_streams=len(streams), max_corners=max_corners)
+    eng = FrontendEngine(cfg, n_streams=len(streams), max_corners=max_corners, inputs_persist=persist)
     out = [[] for _ in streams]
     its = [iter(s.imu) for s in streams]
     pend = [next(it, None) for it in its]

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'libairvision_hip.so')
 AV_MAX_LEVELS = 5
 AV_PYR_BORDER = 16
 AV_OK, AV_E_INVALID, AV_E_HIP, AV_E_CAPACITY, AV_E_NODEVICE = 0, -1, -2, -3, -4
+AV_FE_INPUTS_PERSIST = 1
 
 
 class AirvisionError(RuntimeError):
@@ -36,7 +37,7 @@ class FrontendConfig(C.Structure):
                 ('grid_row', C.c_int32), ('grid_col', C.c_int32),
                 ('grid_min_feature_num', C.c_int32), ('grid_max_feature_num', C.c_int32),
                 ('fast_threshold', C.c_int32), ('lk_win', C.c_int32), ('lk_levels', C.c_int32),
-                ('lk_max_iter', C.c_int32), ('max_corners', C.c_int32), ('reserved0', C.c_int32),
+                ('lk_max_iter', C.c_int32), ('max_corners', C.c_int32), ('flags', C.c_int32),
                 ('lk_eps', C.c_double), ('lk_min_eig', C.c_double), ('stereo_threshold', C.c_double),
                 ('cam0_intrinsics', C.c_double * 4), ('cam0_distortion', C.c_double * 4),
                 ('cam1_intrinsics', C.c_double * 4), ('cam1_distortion', C.c_double * 4),

@@ -95,7 +95,8 @@ __device__ __forceinline__ void av_distort(const CamModel& c, double x, double y
 // pyramid.hip
 int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stride, int n_streams, int imgs_per_stream,
                       const PyrGeom& g, uint8_t* pyr_base, int64_t stream_stride, int64_t slot_stride, int slot0, int slot1,
-                      hipStream_t st);
+                      hipStream_t st, bool write_level0 = true, bool* wrote_level0 = nullptr);
+// write_level0 = false: levels 1.. only, level 0 stays the caller's image (honoured by the fused kernel; *wrote_level0 tells)
 
 // lk.hip
 struct LKParams {
@@ -104,7 +105,8 @@ struct LKParams {
 };
 int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride, int n_set, const PyrGeom& g,
                  const float* prev, float* next, uint8_t* status, const int* count, int cap, int launch_pts,
-                 const LKParams& p, hipStream_t st, const int* index = nullptr);
+                 const LKParams& p, hipStream_t st, const int* index = nullptr,
+                 const uint8_t* imgI = nullptr, int64_t imgI_stride = 0, const uint8_t* imgJ = nullptr, int64_t imgJ_stride = 0);      // level 0 of I / J from the caller's image (lk.hip: LKArgs)
 
 // fast.hip
 void av_fast_tiles(int w, int h, int* tiles, int* tile_cap);         // tile count of a w x h image, entries per tile list

@@ -608,7 +608,12 @@ struct av_frontend {
     // step_host staging: two slots of {pinned host, device} image pairs, a copy stream and events, so that the H2D copy of
     // frame k+1 runs behind the kernels of frame k (pinned double-buffered H2D of frame pairs)
     struct HostSlot { uint8_t* pin = nullptr; uint8_t* dev = nullptr; hipEvent_t copied = nullptr, consumed = nullptr; bool used = false; };
-    HostSlot hs[2]; hipStream_t copy_stream = nullptr; int hs_next = 0;
+    HostSlot hs[3]; hipStream_t copy_stream = nullptr; int hs_next = 0;      // three: the slot of frame k is still read (as the previous cam0 image) by step k+1
+    // Level 0 of a pyramid slot (0 / 1: cam0 of alternating frames, 2: cam1) is either the padded copy inside the slot
+    // (l0_img = nullptr) or the caller's image itself, read in place by LK and FAST (zero copy).  In place is possible when the
+    // image outlives the step that gets it: always for av_frontend_step_host (the library's own staging slots), and for
+    // av_frontend_step when the engine was created with AV_FE_INPUTS_PERSIST (include/airvision.h).
+    const uint8_t* l0_img[3] = {nullptr, nullptr, nullptr}; int64_t l0_stride[3] = {0, 0, 0};
     void* zero_region = nullptr; size_t zero_bytes = 0;
     std::vector<void*> allocs;
     double* dH = nullptr;
@@ -695,7 +700,7 @@ struct Span {
     }
 };
 
-int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t img_stride, const double* ts, hipStream_t st)
+int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t img_stride, const double* ts, hipStream_t st, bool inputs_persist)
 {
     FeDev& d = fe->d;
     const int S = d.S;
@@ -725,8 +730,14 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
     const int cur0 = par ^ 1;                // curr cam0 pyramid slot (0/1), cam1 pyramid is slot 2
     const int64_t sstride = 3 * fe->lay.bytes, slotb = fe->lay.bytes;
     int rc;
+    static const bool zc_off = [] { const char* e = getenv("AV_FE_ZERO_COPY"); return e && atoi(e) == 0; }();      // A/B switch
+    bool wrote_l0 = true;
     { Span sp(fe, 0, st);
-      if ((rc = av_launch_pyramid(img0, img1, img_stride, S, 2, fe->geom, fe->pyr, sstride, slotb, cur0, 2, st))) return rc; }
+      if ((rc = av_launch_pyramid(img0, img1, img_stride, S, 2, fe->geom, fe->pyr, sstride, slotb, cur0, 2, st, !(inputs_persist && !zc_off), &wrote_l0))) return rc; }
+    fe->l0_img[cur0] = wrote_l0 ? nullptr : img0; fe->l0_img[2] = wrote_l0 ? nullptr : img1;
+    fe->l0_stride[cur0] = fe->l0_stride[2] = img_stride;
+    const uint8_t* I_prev0 = fe->l0_img[par]; const int64_t st_prev0 = fe->l0_stride[par];      // (first frame: nothing is tracked from it)
+    const uint8_t* I_cur0 = fe->l0_img[cur0]; const uint8_t* I_cur1 = fe->l0_img[2];
 
     const uint8_t* P_prev0 = fe->pyr + par * slotb;
     const uint8_t* P_cur0 = fe->pyr + cur0 * slotb;
@@ -736,14 +747,14 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
       hipLaunchKernelGGL(track_prepare_kernel, dim3((d.NT + 255) / 256, S), dim3(256), 0, st, d, par);
       AV_LAUNCH_CHECK(); }
     { Span sp(fe, 1, st);
-      if ((rc = av_launch_lk(P_prev0, P_cur0, sstride, S, fe->geom, d.trk_prev, d.trk_next, d.trk_status, d.trk_count, d.NT, d.NT, fe->lk, st))) return rc; }
+      if ((rc = av_launch_lk(P_prev0, P_cur0, sstride, S, fe->geom, d.trk_prev, d.trk_next, d.trk_status, d.trk_count, d.NT, d.NT, fe->lk, st, nullptr, I_prev0, st_prev0, I_cur0, img_stride))) return rc; }
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(track_gate_kernel, dim3(S), dim3(256), 0, st, d);
       AV_LAUNCH_CHECK(); }
     { Span sp(fe, 1, st);
-      if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.sv_p0, d.sv_p1, d.sv_st, d.sv_count, d.NT, d.NT, fe->lk, st))) return rc; }
+      if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.sv_p0, d.sv_p1, d.sv_st, d.sv_count, d.NT, d.NT, fe->lk, st, nullptr, I_cur0, img_stride, I_cur1, img_stride))) return rc; }
     { Span sp(fe, 1, st);
-      if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.sv_p1, d.sv_back, d.sv_st2, d.sv_count, d.NT, d.NT, fe->lk, st))) return rc; }
+      if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.sv_p1, d.sv_back, d.sv_st2, d.sv_count, d.NT, d.NT, fe->lk, st, nullptr, I_cur1, img_stride, I_cur0, img_stride))) return rc; }
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(rebin_kernel, dim3(S), dim3(256), 0, st, d, par);
       AV_LAUNCH_CHECK(); }
@@ -751,26 +762,29 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
     // FAST reads level 0 of the cam0 pyramid built above (same pixels as the input image, with a 16-pixel frame: every
     // tile but the right-most column copies whole dwords without clamping)
     const uint8_t* fast_img = P_cur0 + fe->geom.off[0] + (size_t)AV_PYR_BORDER * fe->geom.pitch[0] + AV_PYR_BORDER;
-    if ((rc = av_launch_fast(fast_img, sstride, fe->geom.pitch[0], AV_PYR_BORDER, nullptr, 0, S, d.w, d.h, fe->cfg.fast_threshold,
-                             nullptr, nullptr, 0, d.tile_kp, d.tile_count, d.counters + CNT_OVF, NCNT, st))) { delete fast_span; return rc; }
+    if (I_cur0) rc = av_launch_fast(I_cur0, img_stride, d.w, 0, nullptr, 0, S, d.w, d.h, fe->cfg.fast_threshold,      // the caller's image in place
+                                    nullptr, nullptr, 0, d.tile_kp, d.tile_count, d.counters + CNT_OVF, NCNT, st);
+    else rc = av_launch_fast(fast_img, sstride, fe->geom.pitch[0], AV_PYR_BORDER, nullptr, 0, S, d.w, d.h, fe->cfg.fast_threshold,
+                             nullptr, nullptr, 0, d.tile_kp, d.tile_count, d.counters + CNT_OVF, NCNT, st);
+    if (rc) { delete fast_span; return rc; }
     delete fast_span;
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(select_kernel, dim3(S), dim3(256), sizeof(int) * (3 * d.C + 1 + d.n_tiles + 1), st, d);
       AV_LAUNCH_CHECK(); }
     const int r1_launch = any_first ? d.CC : d.C * (d.gmax < CAND_R1 ? d.gmax : CAND_R1);
     { Span sp(fe, 1, st);
-      if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.cand_p0, d.cand_p1, d.cand_st, d.r1_count, d.CC, r1_launch, fe->lk, st, d.r1_list))) return rc; }
+      if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.cand_p0, d.cand_p1, d.cand_st, d.r1_count, d.CC, r1_launch, fe->lk, st, d.r1_list, I_cur0, img_stride, I_cur1, img_stride))) return rc; }
     { Span sp(fe, 1, st);
-      if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.r1_count, d.CC, r1_launch, fe->lk, st, d.r1_list))) return rc; }
+      if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.r1_count, d.CC, r1_launch, fe->lk, st, d.r1_list, I_cur1, img_stride, I_cur0, img_stride))) return rc; }
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(cand_round2_kernel, dim3(S), dim3(256), 0, st, d);
       AV_LAUNCH_CHECK(); }
     if (d.gmax > CAND_R1) {                       // round 2: the rest of the cells that are still short of inliers (usually none)
         const int r2_launch = d.C * (d.gmax - CAND_R1);
         { Span sp(fe, 1, st);
-          if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.cand_p0, d.cand_p1, d.cand_st, d.r2_count, d.CC, r2_launch, fe->lk, st, d.r2_list))) return rc; }
+          if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.cand_p0, d.cand_p1, d.cand_st, d.r2_count, d.CC, r2_launch, fe->lk, st, d.r2_list, I_cur0, img_stride, I_cur1, img_stride))) return rc; }
         { Span sp(fe, 1, st);
-          if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.r2_count, d.CC, r2_launch, fe->lk, st, d.r2_list))) return rc; }
+          if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.r2_count, d.CC, r2_launch, fe->lk, st, d.r2_list, I_cur1, img_stride, I_cur0, img_stride))) return rc; }
     }
     size_t fin_lds = sizeof(unsigned long long) * d.NSORT + sizeof(int) * (2 * d.C * d.gmin + 2 * d.C + 3 * (d.C + 1) + 4);
     { Span sp(fe, 3, st);
@@ -893,7 +907,7 @@ AV_EXPORT void av_frontend_destroy(av_frontend* fe)
     (void)hipDeviceSynchronize();
     for (void* p : fe->allocs) (void)hipFree(p);
     for (hipEvent_t e : fe->ev) (void)hipEventDestroy(e);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         av_frontend::HostSlot& h = fe->hs[i];
         if (h.pin) (void)hipHostFree(h.pin);
         if (h.dev) (void)hipFree(h.dev);
@@ -942,7 +956,7 @@ AV_EXPORT int av_frontend_step(av_frontend* fe, const uint8_t* img0_dev, const u
         av_set_error("av_frontend_step: bad arguments");
         return AV_E_INVALID;
     }
-    return step_impl(fe, img0_dev, img1_dev, img_stride, timestamps, (hipStream_t)stream);
+    return step_impl(fe, img0_dev, img1_dev, img_stride, timestamps, (hipStream_t)stream, (fe->cfg.flags & AV_FE_INPUTS_PERSIST) != 0);
 }
 
 AV_EXPORT int av_frontend_step_host(av_frontend* fe, const uint8_t* img0_host, const uint8_t* img1_host, int64_t img_stride,
@@ -957,7 +971,7 @@ AV_EXPORT int av_frontend_step_host(av_frontend* fe, const uint8_t* img0_host, c
     const int S = fe->d.S;
     AV_HIP(hipSetDevice(fe->device));
     av_frontend::HostSlot& h = fe->hs[fe->hs_next];
-    fe->hs_next ^= 1;
+    fe->hs_next = (fe->hs_next + 1) % 3;
     if (!fe->copy_stream) AV_HIP(hipStreamCreateWithFlags(&fe->copy_stream, hipStreamNonBlocking));
     if (!h.pin) {
         AV_HIP(hipHostMalloc((void**)&h.pin, 2 * img_bytes * S, hipHostMallocDefault));
@@ -965,7 +979,9 @@ AV_EXPORT int av_frontend_step_host(av_frontend* fe, const uint8_t* img0_host, c
         AV_HIP(hipEventCreateWithFlags(&h.copied, hipEventDisableTiming));
         AV_HIP(hipEventCreateWithFlags(&h.consumed, hipEventDisableTiming));
     }
-    if (h.used) AV_HIP(hipEventSynchronize(h.consumed));          // the step that last used this slot (two calls ago) has read it
+    // the slot was filled three calls ago and last read two calls ago (as that step's previous cam0 image): wait for the
+    // step recorded after it -- every earlier step on the stream has then retired too
+    if (h.used) AV_HIP(hipEventSynchronize(h.consumed));
     // caller memory -> pinned slot (the caller's buffers are free again when this returns), all cores
 #pragma omp parallel for schedule(static) num_threads(S >= 16 ? 8 : 1)
     for (int i = 0; i < 2 * S; ++i) {
@@ -975,8 +991,11 @@ AV_EXPORT int av_frontend_step_host(av_frontend* fe, const uint8_t* img0_host, c
     AV_HIP(hipMemcpyAsync(h.dev, h.pin, 2 * img_bytes * S, hipMemcpyHostToDevice, fe->copy_stream));
     AV_HIP(hipEventRecord(h.copied, fe->copy_stream));
     AV_HIP(hipStreamWaitEvent(st, h.copied, 0));
-    const int rc = step_impl(fe, h.dev, h.dev + img_bytes * S, (int64_t)img_bytes, timestamps, st);
+    const int rc = step_impl(fe, h.dev, h.dev + img_bytes * S, (int64_t)img_bytes, timestamps, st, true);      // staging slots outlive the next step
     if (rc) return rc;
+    // `consumed` of the slot filled ONE call ago is recorded now: this step was the last reader of its cam0 image
+    av_frontend::HostSlot& hp = fe->hs[(fe->hs_next + 1) % 3];
+    if (hp.pin) { AV_HIP(hipEventRecord(hp.consumed, st)); hp.used = true; }
     AV_HIP(hipEventRecord(h.consumed, st));
     h.used = true;
     return AV_OK;

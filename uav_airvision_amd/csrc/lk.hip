@@ -54,6 +54,12 @@ struct LKArgs {
     int cap;
     int max_iter;
     double eps2, min_eig;
+    int n_set, gx;              // XCD-aware 1-D launch (gx > 0): gx workgroups per point set, see lk_track_g16_body
+    // Level 0 straight from the caller's image (w x h, tightly packed rows) instead of a padded copy in the pyramid: non-null =
+    // the I (resp. J) side reads level 0 at img + set * img_stride, with BORDER_REFLECT_101 indexing for the few windows that
+    // reach over the image border (what the padded level's frame holds).  Levels >= 1 always come from the padded pyramid.
+    const uint8_t* imgI; const uint8_t* imgJ;
+    int64_t imgI_stride, imgJ_stride;
 };
 
 // LDS traffic of one wave is ordered by issue; this keeps the compiler from moving a read of the
@@ -248,8 +254,15 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
     const int g = threadIdx.x >> 4;                 // point slot of this 16-lane group inside the workgroup
     const int r = threadIdx.x & 15;                 // window row owned by this lane (row 15 only feeds row 14)
     uint32_t* tile = tile_all[g];
-    const int s = blockIdx.y;
-    const int slot = blockIdx.x * 16 + g;
+    // Workgroup -> (point set, block of 16 points).  The dispatcher deals workgroups round-robin over the 8 XCDs (linear id mod 8,
+    // MI355X_MICROARCH.md "Workgroup dispatch"), and each XCD has its own L2: with the plain (block, set) grid the ~19 workgroups of
+    // one stream land on all eight XCDs and every L2 fetches that stream's two pyramids (profiles/r03/fetch_calib.json, rows32: a
+    // window gather in image order reads 2.6x the image bytes).  The 1-D launch keeps a set's workgroups on ONE XCD: id L ->
+    // XCD label L & 7, set = label + 8 * ((L >> 3) / gx), block = (L >> 3) % gx.  Placement only: any mapping is correct.
+    int s, bx;
+    if (a.gx > 0) { const int L = blockIdx.x, j = L >> 3; s = (L & 7) + 8 * (j / a.gx); bx = j % a.gx; if (s >= a.n_set) return; }
+    else { s = blockIdx.y; bx = blockIdx.x; }
+    const int slot = bx * 16 + g;
     const int n = min(a.count[s], a.cap);
     if (slot >= n) return;                          // uniform per 16-lane group
     const int pidx = a.index ? a.index[(size_t)s * a.cap + slot] : slot;
@@ -295,21 +308,38 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
         const int sub = r >> 3, dwl = r & 7;
         const uint32_t tofs = (uint32_t)(sub * (TPITCH / 4) + dwl);
         wave_lds_sync();
+        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
         {
-            typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-            const uint8_t* L0 = PI + a.g.off[level];                    // padded origin of the level: row -16, column -16
+            // source of this level's I rows: the padded pyramid level (origin at row -16, column -16, frame included) or, for
+            // level 0 in place, the caller's image (origin at pixel (0, 0), no frame: windows over the border take the slow path)
+            const bool extI = level == 0 && a.imgI != nullptr;                      // wave-uniform
+            const uint8_t* L0 = extI ? a.imgI + (size_t)s * (size_t)a.imgI_stride : PI + a.g.off[level];
+            const int pI = extI ? w : pitch, bI = extI ? 0 : AV_PYR_BORDER;
             const bool act = dwl < 5;                                    // 5 of the 8 slots of a row carry a dword
-            const uint32_t loff = (uint32_t)(__mul24(ipy - 1 + sub + AV_PYR_BORDER, pitch) + (ipx - 1 + AV_PYR_BORDER) + (dwl < 4 ? 4 * dwl : 14));
-            const uint32_t shamt = dwl == 4 ? 16u : 0u;
-            uint32_t sv[9];
+            if (!extI || (ipx >= 1 && ipx + 16 < w && ipy >= 1 && ipy + 16 < h)) {
+                const uint32_t loff = (uint32_t)(__mul24(ipy - 1 + sub + bI, pI) + (ipx - 1 + bI) + (dwl < 4 ? 4 * dwl : 14));
+                const uint32_t shamt = dwl == 4 ? 16u : 0u;
+                uint32_t sv[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {                               // 18 rows
-                sv[k] = 0;
-                if (act) sv[k] = *reinterpret_cast<const u32_unaligned*>(L0 + (size_t)(2 * k) * (size_t)pitch + loff);
+                for (int k = 0; k < 9; ++k) {                               // 18 rows
+                    sv[k] = 0;
+                    if (act) sv[k] = *reinterpret_cast<const u32_unaligned*>(L0 + (size_t)(2 * k) * (size_t)pI + loff);
+                }
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    if (act) tile[tofs + 2 * k * (TPITCH / 4)] = sv[k] >> shamt;
+            } else if (act) {
+                // the window reaches over the image border: the bytes the padded level's BORDER_REFLECT_101 frame would hold
+                const int xb = ipx - 1 + (dwl < 4 ? 4 * dwl : 16), nbyte = dwl < 4 ? 4 : 2;
+#pragma unroll 1
+                for (int k = 0; k < 9; ++k) {
+                    const uint8_t* row = L0 + (size_t)av_reflect101(ipy - 1 + sub + 2 * k, h) * (size_t)w;
+                    uint32_t v = 0;
+#pragma unroll 1
+                    for (int bb = 0; bb < nbyte; ++bb) v |= (uint32_t)row[av_reflect101(xb + bb, w)] << (8 * bb);
+                    tile[tofs + 2 * k * (TPITCH / 4)] = v;
+                }
             }
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-                if (act) tile[tofs + 2 * k * (TPITCH / 4)] = sv[k] >> shamt;
         }
         wave_lds_sync();
 
@@ -422,14 +452,29 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
                 X0 = min(max((inx - 6) & ~3, col_lo), col_hi - TILE_COLS);
                 Y0 = min(max(iny - 4, -AV_PYR_BORDER), h + AV_PYR_BORDER - TILE_ROWS);
                 wave_lds_sync();
-                const uint8_t* LJ0 = PJ + a.g.off[level];
-                const uint32_t joff = (uint32_t)(__mul24(Y0 + sub + AV_PYR_BORDER, pitch) + X0 + AV_PYR_BORDER + 4 * dwl);
-                uint32_t sv[TILE_ROWS / 2];
+                {
+                    const bool extJ = level == 0 && a.imgJ != nullptr;              // wave-uniform
+                    const uint8_t* LJ0 = extJ ? a.imgJ + (size_t)s * (size_t)a.imgJ_stride : PJ + a.g.off[level];
+                    const int pJ = extJ ? w : pitch, bJ = extJ ? 0 : AV_PYR_BORDER;
+                    if (!extJ || (X0 >= 0 && X0 + TILE_COLS <= w && Y0 >= 0 && Y0 + TILE_ROWS <= h)) {
+                        const uint32_t joff = (uint32_t)(__mul24(Y0 + sub + bJ, pJ) + X0 + bJ + 4 * dwl);
+                        uint32_t sv[TILE_ROWS / 2];
 #pragma unroll
-                for (int k = 0; k < TILE_ROWS / 2; ++k)        // 24 rows x 8 dwords
-                    sv[k] = *reinterpret_cast<const uint32_t*>(LJ0 + (size_t)(2 * k) * (size_t)pitch + joff);
+                        for (int k = 0; k < TILE_ROWS / 2; ++k)        // 24 rows x 8 dwords
+                            sv[k] = *reinterpret_cast<const u32_unaligned*>(LJ0 + (size_t)(2 * k) * (size_t)pJ + joff);
 #pragma unroll
-                for (int k = 0; k < TILE_ROWS / 2; ++k) tile[tofs + 2 * k * (TPITCH / 4)] = sv[k];
+                        for (int k = 0; k < TILE_ROWS / 2; ++k) tile[tofs + 2 * k * (TPITCH / 4)] = sv[k];
+                    } else {
+#pragma unroll 1
+                        for (int k = 0; k < TILE_ROWS / 2; ++k) {
+                            const uint8_t* row = LJ0 + (size_t)av_reflect101(Y0 + sub + 2 * k, h) * (size_t)w;
+                            uint32_t v = 0;
+#pragma unroll 1
+                            for (int bb = 0; bb < 4; ++bb) v |= (uint32_t)row[av_reflect101(X0 + 4 * dwl + bb, w)] << (8 * bb);
+                            tile[tofs + 2 * k * (TPITCH / 4)] = v;
+                        }
+                    }
+                }
                 wave_lds_sync();
                 staged = true;
                 dx0 = inx - X0; dy0 = iny - Y0;
@@ -481,13 +526,14 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
 
 // 96 VGPRs: 5 waves per SIMD without spills (the kernel is VALU-issue bound: 4 -> 5 waves bought 1 %, a 6-wave build with
 // 11 spilled values lost 5 %).
-template <int WIN> __global__ __launch_bounds__(256, 4) void lk_track_g16_kernel(LKArgs a) { lk_track_g16_body<WIN, 4>(a); }
+template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_kernel(LKArgs a) { lk_track_g16_body<WIN, 5>(a); }
 
 }  // namespace
 
 int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride, int n_set, const PyrGeom& g,
                  const float* prev, float* next, uint8_t* status, const int* count, int cap, int launch_pts,
-                 const LKParams& p, hipStream_t st, const int* index)
+                 const LKParams& p, hipStream_t st, const int* index,
+                 const uint8_t* imgI, int64_t imgI_stride, const uint8_t* imgJ, int64_t imgJ_stride)
 {
     if (n_set <= 0 || launch_pts <= 0) return AV_OK;
     if (p.win != 15) {
@@ -499,8 +545,12 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
     a.pyrI = pyrI; a.pyrJ = pyrJ; a.stream_stride = stream_stride; a.g = g;
     a.prev = prev; a.next = next; a.status = status; a.count = count; a.index = index; a.cap = cap;
     a.max_iter = p.max_iter; a.eps2 = p.eps2; a.min_eig = p.min_eig;
+    a.imgI = imgI; a.imgJ = imgJ; a.imgI_stride = imgI_stride; a.imgJ_stride = imgJ_stride;
     if (launch_pts > cap) launch_pts = cap;
-    dim3 grid((launch_pts + 15) / 16, n_set);
+    static const bool xcd_map = [] { const char* e = getenv("AV_LK_XCD"); return !(e && atoi(e) == 0); }();      // A/B switch
+    const int gx = (launch_pts + 15) / 16;
+    a.n_set = n_set; a.gx = xcd_map ? gx : 0;
+    dim3 grid = xcd_map ? dim3((unsigned)gx * 8u * (unsigned)((n_set + 7) / 8)) : dim3(gx, n_set);
     hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;

@@ -1725,20 +1725,10 @@ __global__ __launch_bounds__(256) void upd_s_kernel(const UpdArgs* __restrict__ 
 // grid: three barriers per EIGHT columns (the unblocked form pays one per column, and the barrier is most of a step at
 // these sizes).  L goes back to Sbuf (row-major) for the substitution kernel, which reads it through the scalar cache.
 constexpr int CNB = 8;
-__global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict__ arr)
+// in-place blocked Cholesky of the packed lower triangle Lp (k x k) by a 256-thread workgroup; ends on a barrier
+__device__ __forceinline__ void chol_packed_lds(double* Lp, int k, int tid)
 {
-    AV_FILTER_PRIO();
-    extern __shared__ double Lp[];
-    const UpdArgs a = arr[blockIdx.x];
-    if (a.m <= 0 || a.mode != 0) return;
-    const int tid = threadIdx.x;
-    const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
     auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
-    for (int e = tid; e < k * k; e += 256) {
-        const int r = e / k, c = e - r * k;
-        if (c <= r) at(r, c) = a.Sbuf[(size_t)r * a.ld + c];
-    }
-    __syncthreads();
     for (int j0 = 0; j0 < k; j0 += CNB) {
         const int nb = min(CNB, k - j0), jb = j0 + nb;
         if (tid == 0) {                                    // diagonal block: Cholesky of nb x nb in registers
@@ -1798,6 +1788,22 @@ __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict
         }
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict__ arr)
+{
+    AV_FILTER_PRIO();
+    extern __shared__ double Lp[];
+    const UpdArgs a = arr[blockIdx.x];
+    if (a.m <= 0 || a.mode != 0) return;
+    const int tid = threadIdx.x;
+    const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
+    auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
+    for (int e = tid; e < k * k; e += 256) {
+        const int r = e / k, c = e - r * k;
+        if (c <= r) at(r, c) = a.Sbuf[(size_t)r * a.ld + c];
+    }
+    __syncthreads();
+    chol_packed_lds(Lp, k, tid);
     // L is written as a symmetric matrix: the substitution kernel reads eight consecutive rows of one COLUMN of L per step,
     // which the mirrored upper triangle holds contiguously (one 64-byte scalar load instead of eight)
     for (int e = tid; e < k * k; e += 256) {
@@ -2103,6 +2109,114 @@ __global__ __launch_bounds__(256) void upd_gather_kernel(const UpdArgs* __restri
     }
 }
 // ================================================================================================
+// Row compression WITHOUT a QR for the streams that stack more rows than one back-end pass keeps (m > 144 over n_c <= 144 columns).
+// With isotropic noise the update depends on the stacked Jacobian only through A = Hc^T Hc and b = Hc^T r (information form:
+// P+ = (P^-1 + A / s^2)^-1, dx = P+ b / s^2), so ANY (F, f) with F^T F = A and F^T f = b may stand in for (H, r) -- the thin QR's
+// (R, Q^T r) that msckf.py:554-557 uses is one such pair, the Cholesky factor of the Gram matrix another:
+//      [A + E  b; b^T  rho] = L L^T  (bordered, E = 1e-12 diag(A)),   F = L_nc^T,   f = L_nc^-1 b = the border row of L.
+// A is singular (the projected Jacobian is blind to a rigid motion of the observing cameras), hence E: a relative 1e-12 on the
+// diagonal, six orders below the 1e-6 parity tolerance and four above the rounding of the sums.  The Gram matrix is a sum over the
+// rows -- a wide-grid tile GEMM, split over chunks of 256 rows with the partial sums added in a fixed order (no atomics) -- and the
+// only dependent chain is one n_c-sized Cholesky in a 256-thread workgroup.  This replaces update_front_batch_kernel (a
+// 1024-thread, 128-VGPR Householder workgroup that had to wait ~1 ms for a whole free CU) on the batched path.
+//   upd_rowmap_kernel     stacked row -> row of the block buffer (scan of the gated blocks), int[m] in the stream's Kt buffer
+//   upd_gram_kernel       partial Gram slabs of [Hc | r] per (64 x 64 lower tile, 256-row chunk), in the stream's W buffer
+//   upd_gram_chol_kernel  sum of the slabs -> bordered Cholesky in LDS -> [F | f] written as the k = n_c rows of W
+// ================================================================================================
+constexpr int GRAM_CHUNK = 256;
+__device__ __forceinline__ bool upd_front_needed(const UpdArgs& a) { return a.m > 0 && a.mode == 0 && a.kdir <= 0 && upd_compress(a.m, a.nc); }
+
+__global__ __launch_bounds__(256) void upd_rowmap_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list)
+{
+    AV_FILTER_PRIO();
+    const UpdArgs a = arr[list[blockIdx.x]];
+    if (!upd_front_needed(a)) return;
+    __shared__ int wsum[4], carry;
+    int* srcrow = reinterpret_cast<int*>(a.Kt);
+    const int tid = threadIdx.x, nb = a.n_blk;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 256) {               // blocks in order: exclusive scan of their lengths, 256 at a time
+        const int b = b0 + tid;
+        const int len = b < nb ? a.blk_len[b] : 0;
+        int incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if ((tid & 63) >= d) incl += t; }
+        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        __syncthreads();
+        int base = carry;
+        for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+        const int d0 = base + incl - len;
+        if (b < nb) { const int r0 = a.blk_row[b]; for (int r = 0; r < len; ++r) srcrow[d0 + r] = r0 + r; }
+        __syncthreads();
+        if (tid == 255) carry = base + incl;
+        __syncthreads();
+    }
+}
+
+// slab (chunk y) of the Gram matrix of G = [Hc | r] (m x (nc + 1)): tile x of the lower 64 x 64 tiles
+__global__ __launch_bounds__(256) void upd_gram_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list)
+{
+    AV_FILTER_PRIO();
+    const UpdArgs a = arr[list[blockIdx.z]];
+    if (!upd_front_needed(a)) return;
+    const int m = a.m, nc = a.nc, k1 = nc + 1;
+    const int row0 = blockIdx.y * GRAM_CHUNK;
+    if (row0 >= m) return;
+    const int rows = min(GRAM_CHUNK, m - row0);
+    int tr = (int)((sqrtf(8.f * blockIdx.x + 1.f) - 1.f) * 0.5f);              // triangular tile index -> (tr, tc), tc <= tr
+    while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
+    while (tr * (tr + 1) / 2 > (int)blockIdx.x) --tr;
+    const int tc = blockIdx.x - tr * (tr + 1) / 2;
+    const int r0 = tr * GT, c0 = tc * GT;
+    if (r0 >= k1) return;
+    const int* srcrow = reinterpret_cast<const int*>(a.Kt) + row0;
+    auto elem = [&](int q, int c) -> double {            // G[row0 + q][c]
+        if (c >= k1) return 0.0;
+        const size_t sr = (size_t)srcrow[q];
+        return c < nc ? a.Hsrc[sr * a.ld + a.cols[c]] : a.rsrc[sr];
+    };
+    double acc[4][4];
+    gemm_tile64(rows, r0, c0, elem, elem, acc);
+    double* slab = a.W + (size_t)blockIdx.y * k1 * k1;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + 4 * ty + i, c = c0 + 4 * tx + j;
+            if (r < k1 && c <= r) slab[(size_t)r * k1 + c] = acc[i][j];
+        }
+}
+
+__global__ __launch_bounds__(256) void upd_gram_chol_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list)
+{
+    AV_FILTER_PRIO();
+    extern __shared__ double Lp[];
+    const UpdArgs a = arr[list[blockIdx.x]];
+    if (!upd_front_needed(a)) return;
+    const int tid = threadIdx.x, m = a.m, nc = a.nc, k1 = nc + 1;
+    const int nsl = (m + GRAM_CHUNK - 1) / GRAM_CHUNK;
+    auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
+    for (int e = tid; e < k1 * k1; e += 256) {
+        const int r = e / k1, c = e - r * k1;
+        if (c > r) continue;
+        double v = 0;
+        for (int y = 0; y < nsl; ++y) v += a.W[(size_t)y * k1 * k1 + (size_t)r * k1 + c];      // fixed order: deterministic
+        if (r == c) v = r < nc ? v + (1e-12 * v + 1e-300) : 2.0 * v + 1.0;                      // E on the diagonal; the border pivot only has to stay positive
+        at(r, c) = v;
+    }
+    __syncthreads();
+    chol_packed_lds(Lp, k1, tid);
+    const size_t ldt = a.ldt;
+    for (int e = tid; e < nc * nc; e += 256) {           // W[q][row] = F[row][q] = L[q][row] (row <= q), the k = nc rows the back end reads
+        const int q = e / nc, row = e - q * nc;
+        a.W[(size_t)q * ldt + row] = row <= q ? at(q, row) : 0.0;
+    }
+    double* rcol = a.W + (size_t)nc * ldt;
+    for (int row = tid; row < nc; row += 256) rcol[row] = at(nc, row);
+}
+// ================================================================================================
 // Stacking decisions of remove_lost_features / prune_cam_state_buffer ON THE DEVICE (msckf.py:658-668, 759-763): which gated
 // blocks are stacked (in feature = map order, up to the `> 1500 rows` cut), which camera columns they touch, and how the
 // stacked rows are split into the sequential chunks of the batched back end.  One wavefront per stream.  The host only
@@ -2226,8 +2340,9 @@ static int msckf_lds_opt_in()
         const int lim = 160 * 1024;
         const void* fns[5] = {reinterpret_cast<const void*>(feature_kernel<16>), reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
                               reinterpret_cast<const void*>(update_front_kernel), reinterpret_cast<const void*>(update_front_batch_kernel)};
-        const void* fns2[4] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel),
-                               reinterpret_cast<const void*>(upd_chol_kernel), reinterpret_cast<const void*>(upd_info_kernel)};
+        const void* fns2[5] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel),
+                               reinterpret_cast<const void*>(upd_chol_kernel), reinterpret_cast<const void*>(upd_info_kernel),
+                               reinterpret_cast<const void*>(upd_gram_chol_kernel)};
         for (const void* f : fns2) {
             hipFuncAttributes at;
             hipError_t e = hipFuncGetAttributes(&at, f);

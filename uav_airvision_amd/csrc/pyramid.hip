@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void pad_level0_kernel(PyrArgs a)
 // 16 pixels of the image border (the frame of level 1).  The separate pad and first pyrDown kernels read the image and
 // re-read the padded level 0 (0.8 MB per image through L2); here every input byte is read once.
 constexpr int FT_W = 128, FT_H = 32, FT_LP = FT_W + 8;        // LDS row: columns x0-4 .. x0+131
+template <bool WRITE_L0>
 __global__ __launch_bounds__(256) void pyr_l0l1_kernel(PyrArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t src[(FT_H + 4) * FT_LP];
@@ -134,7 +135,9 @@ __global__ __launch_bounds__(256) void pyr_l0l1_kernel(PyrArgs a)
     __syncthreads();
 
     // ---- padded level 0: destination rows / 16-byte chunks owned by this tile (interior + its share of the frame) ----
-    {
+    //      (WRITE_L0 = false: level 0 stays the caller's image -- LK and FAST read it in place, lk.hip LKArgs::imgI -- which
+    //       removes 401 KB of stores and the re-read of that copy per image: 44 % of this kernel's bytes)
+    if (WRITE_L0) {
         const bool top = y0 == 0, bot = y0 + FT_H >= h, left = x0 == 0, right = x0 + FT_W >= w;
         const int tw = min(FT_W, w - x0);                                 // valid interior columns (multiple of 16 or the image's tail)
         const int nrow = FT_H + (top ? AV_PYR_BORDER : 0) + (bot ? AV_PYR_BORDER : 0);
@@ -388,8 +391,9 @@ PyrGeom av_make_geom(const av_pyr_layout& l)
 
 int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stride, int n_streams, int imgs_per_stream,
                       const PyrGeom& g, uint8_t* pyr_base, int64_t stream_stride, int64_t slot_stride, int slot0, int slot1,
-                      hipStream_t st)
+                      hipStream_t st, bool write_level0, bool* wrote_level0)
 {
+    if (wrote_level0) *wrote_level0 = true;
     if (n_streams <= 0) return AV_OK;
     PyrArgs a;
     a.img0 = img0; a.img1 = img1; a.img_stride = img_stride; a.imgs_per_stream = imgs_per_stream;
@@ -404,7 +408,8 @@ int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stri
                        !getenv("AV_PYR_UNFUSED");
     if (fused) {
         dim3 grid((w + FT_W - 1) / FT_W, h / FT_H, n_img);
-        hipLaunchKernelGGL(pyr_l0l1_kernel, grid, dim3(256), 0, st, a);
+        if (write_level0) hipLaunchKernelGGL(pyr_l0l1_kernel<true>, grid, dim3(256), 0, st, a);
+        else { hipLaunchKernelGGL(pyr_l0l1_kernel<false>, grid, dim3(256), 0, st, a); if (wrote_level0) *wrote_level0 = false; }
         AV_LAUNCH_CHECK();
     } else {
         int chunks = (g.pitch[0] >> 4) * (g.h[0] + 2 * AV_PYR_BORDER);

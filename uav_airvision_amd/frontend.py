@@ -63,11 +63,17 @@ COUNTER_NAMES = ('before_tracking', 'after_tracking', 'after_matching', 'n_fast'
 
 
 class FrontendEngine(object):
-    def __init__(self, config, n_streams=1, device=0, max_corners=8192):
+    def __init__(self, config, n_streams=1, device=0, max_corners=8192, inputs_persist=False):
+        """inputs_persist: promise that the cuda tensors handed to `step` stay unmodified until the NEXT step has run
+        (AV_FE_INPUTS_PERSIST, include/airvision.h): pyramid level 0 is then read in place instead of being copied.  The engine
+        keeps a reference to the last cam0 tensor, so dropping yours is fine; overwriting it in place is not.  `step_host`
+        always works in place on the library's own staging slots.  Same results either way."""
         self.config = config
         self.n_streams = int(n_streams)
         self.device = int(device)
         self._cfg = pack_frontend_config(config, max_corners)
+        self._cfg.flags = N.AV_FE_INPUTS_PERSIST if inputs_persist else 0
+        self._keep = None
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             N.check(N.lib().av_frontend_create(C.byref(self._cfg), self.n_streams, self.device, C.byref(self._h)))
@@ -114,6 +120,7 @@ class FrontendEngine(object):
         ts = (C.c_double * S)(*[float(t) for t in timestamps])
         with torch.cuda.device(self.device):
             N.check(N.lib().av_frontend_step(self._h, N.dptr(img0), N.dptr(img1), self.height * self.width, ts, self._stream()))
+        self._keep = (self._keep[1] if self._keep else None, (img0, img1))       # this frame's and the previous frame's tensors stay alive
 
     def step_host(self, img0, img1, timestamps):
         """numpy uint8 [S,h,w] (or [h,w] when S == 1)."""
