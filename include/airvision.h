@@ -323,6 +323,16 @@ int  av_msckf_batch_stream_status(av_msckf_batch* b, int stream_idx, int32_t* st
  * reallocations after the first step (0 in a correctly pre-sized run), min camera states, max camera states,
  * min map features, max map features].  bench.py uses it to prove that the timed region is the steady state. */
 int  av_msckf_batch_counters(av_msckf_batch* b, int64_t out8[8]);
+/* Parity-test tap (SURVEY 8b "get_state / get_cov for parity tests"): the values the reference computes inside gating_test and
+ * measurement_update (msckf.py:604-612, 548-602) but never returns.  After av_msckf_batch_debug_capture(b, 1) every stream keeps
+ * them for the two update phases of its LAST step: phase 0 = remove_lost_features, 1 = prune_cam_state_buffer.  debug_read:
+ * gamma[*n_gamma] in the reference's evaluation order (features behind the > 1500-row cut are not evaluated, msckf.py:667-668);
+ * *rows = stacked rows of the phase's update (0: no update ran, dx / P_after untouched); dx[*n_state]; P_after[*n_state ** 2]
+ * = state_cov right after the update (before the pruning phase removes its two camera states).  P_after rows have pitch
+ * *n_state; n_cap = capacity of dx (n_cap doubles) and P_after (n_cap * n_cap).  Synchronous copies per step: tests only. */
+int  av_msckf_batch_debug_capture(av_msckf_batch* b, int enable);
+int  av_msckf_batch_debug_read(av_msckf_batch* b, int stream_idx, int phase, double* gamma, int gamma_cap, int32_t* n_gamma,
+                               double* dx, double* P_after, int n_cap, int32_t* n_state, int32_t* rows);
 /* Work done so far, for the filter stage's roofline (drain first): out8 = [algorithmic fp64 flops of the gating tests
  * (per feature with r = 4M-3 rows, n columns: 2rn^2 + 2r^2n + r^3/3; msckf.py:604-612), of the measurement updates on the
  * k = min(m, n) rows kept (S 2kn^2 + 2k^2n, Cholesky k^3/3, solve 2k^2n, (I-KH)P 4kn^2; msckf.py:562-602), of the reference's

@@ -12,27 +12,39 @@ def stream_of(cfg, g):
 
 
 def run_recording(flt, fs, get_P, get_state):
-    """flt needs .debug with 'gamma' (list, appended per gate) and 'delta_x' (set per update), like both
-    oracle.msckf_np.OracleMSCKF and dropin.msckf.MSCKF."""
+    """flt needs .debug with 'gamma' (list, appended per gate) and either a `measurement_update` method that sets
+    debug['delta_x'] (oracle.msckf_np.OracleMSCKF, tests/stepwise_msckf.MSCKF: wrapped here to catch the covariance right after
+    every update) or `capture_debug` (the drop-in view over the batched filter: the library hands out delta_x and P+ of the
+    frame's updates in debug['updates'])."""
     rec = dict(gamma=[], gate_frame=[], upd_frame=[], upd_dx=[], upd_Pdiag=[], upd_Ptrace=[], upd_P={}, frames=[])
-    orig_upd = flt.measurement_update
     k = [0]
 
-    def upd(H, r, *a, **kw):
-        flt.debug.pop('delta_x', None)
-        out = orig_upd(H, r, *a, **kw)
-        if 'delta_x' in flt.debug:
-            P = get_P()
-            rec['upd_frame'].append(k[0]); rec['upd_dx'].append(np.array(flt.debug['delta_x']))
-            rec['upd_Pdiag'].append(np.diag(P).copy()); rec['upd_Ptrace'].append(np.trace(P))
-            rec['upd_P'][len(rec['upd_frame']) - 1] = P.copy() if (len(rec['upd_frame']) - 1) % 16 == 0 else None
-        return out
-    flt.measurement_update = upd
+    def note(dx, P):
+        rec['upd_frame'].append(k[0]); rec['upd_dx'].append(np.array(dx))
+        rec['upd_Pdiag'].append(np.diag(P).copy()); rec['upd_Ptrace'].append(np.trace(P))
+        rec['upd_P'][len(rec['upd_frame']) - 1] = P.copy() if (len(rec['upd_frame']) - 1) % 16 == 0 else None
+
+    view = hasattr(flt, 'capture_debug')
+    if view:
+        flt.capture_debug(True)
+    else:
+        orig_upd = flt.measurement_update
+
+        def upd(H, r, *a, **kw):
+            flt.debug.pop('delta_x', None)
+            out = orig_upd(H, r, *a, **kw)
+            if 'delta_x' in flt.debug:
+                note(flt.debug['delta_x'], get_P())
+            return out
+        flt.measurement_update = upd
 
     def on(msg):
         flt.debug['gamma'] = []
         res = flt.feature_callback(msg)
         rec['gamma'].extend(flt.debug['gamma']); rec['gate_frame'].extend([k[0]] * len(flt.debug['gamma']))
+        if view:
+            for _rows, dx, P in flt.debug.get('updates', []):
+                note(dx, P)
         st = get_state(); st['published'] = res is not None
         rec['frames'].append(st)
         k[0] += 1

@@ -35,3 +35,24 @@ def test_committed_bench_line_has_the_contract_fields():
     # value = streams * steps / time
     s = d['config']['streams_per_gpu'] * d['n_gpus']
     assert abs(d['value'] - s / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
+
+
+def test_pmc_constants_come_from_the_committed_summary():
+    """bench.py has no hard-coded counter values: the traffic / VALU figures of `roofline` are read from the newest committed
+    rocprofv3 PMC summary, and a committed round-3 bench line must carry exactly those values."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    path = os.path.join(ROOT, bench.LK_PMC['path'])
+    e = json.load(open(path))['lk_track_g16_kernel<15>']
+    assert bench.LK_PMC['fetch_kb'] == e['FETCH_SIZE'] and bench.LK_PMC['write_kb'] == e['WRITE_SIZE'] and bench.LK_PMC['valu'] == e['SQ_INSTS_VALU']
+    assert bench.LK_TRAFFIC_BYTES_PER_LAUNCH_S64 == (bench.FETCH_SIZE_FACTOR * e['FETCH_SIZE'] + e['WRITE_SIZE']) * 1024
+    calib = json.load(open(os.path.join(ROOT, 'profiles', 'r03', 'fetch_calib.json')))['kernels']
+    for k in ('read16', 'read4', 'read1'):                      # the measured factor: FETCH_SIZE reports half of the bytes, whatever the lane width
+        assert abs(1.0 / calib[k]['raw_over_known'] - bench.FETCH_SIZE_FACTOR) < 0.01, k
+    lines = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r03', 'bench_*.json')))
+    for f in lines:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        if 'pmc_constants' in d and d['pmc_constants']['path'] == bench.LK_PMC['path']:
+            assert d['pmc_constants']['fetch_kb'] == e['FETCH_SIZE'] and d['pmc_constants']['valu'] == e['SQ_INSTS_VALU'], f

@@ -18,8 +18,11 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(ROOT, 'tests', 'golden')
 
 
-@pytest.fixture(scope='module')
-def dropin():
+@pytest.fixture(scope='module', params=['view', 'stepwise'])
+def dropin(request):
+    """(filter module, feature module).  'view' = the product: dropin/msckf.py, a view over the batched C++/HIP filter with one
+    stream; 'stepwise' = tests/stepwise_msckf.py, the Python driver that sequences the single-filter operator API
+    (av_msckf_propagate / _feature_blocks / _update ...), so those entry points stay under the same reference vectors."""
     import torch
     assert torch.cuda.is_available()
     d = os.path.join(ROOT, 'uav_airvision_amd', 'dropin')
@@ -27,6 +30,9 @@ def dropin():
         sys.path.insert(0, d)
     import msckf as dmsckf
     import feature as dfeature
+    if request.param == 'stepwise':
+        import stepwise_msckf
+        return stepwise_msckf, dfeature
     return dmsckf, dfeature
 
 
@@ -72,6 +78,8 @@ def test_operator_parity_along_a_run(dropin, cfg):
     dmsckf, _ = dropin
     fs = SyntheticFeatureStream(cfg, seed=7, n_frames=40, n_features=80)
     gpu = dmsckf.MSCKF(cfg, write_trajectory=False)
+    if hasattr(gpu, 'capture_debug'):
+        gpu.capture_debug(True)
     ora = OracleMSCKF(cfg)
     it = iter(fs.imu); pend = next(it, None)
     worst = 0.0

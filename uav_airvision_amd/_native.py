@@ -99,6 +99,8 @@ SIGNATURES = {
     'av_quat_multiply': (C.c_int, [_P, _P, _P]),
     'av_quat_small_angle': (C.c_int, [_P, _P]),
     'av_quat_from_two_vectors': (C.c_int, [_P, _P, _P]),
+    'av_msckf_batch_debug_capture': (C.c_int, [_P, C.c_int]),
+    'av_msckf_batch_debug_read': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int32), _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'av_msckf_batch_work': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double * 8)]),
     'av_msckf_batch_get_state': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double * 32), _P, _P, C.c_int, C.POINTER(C.c_int32)]),
     'av_msckf_batch_stream_status': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_char_p, C.c_int]),

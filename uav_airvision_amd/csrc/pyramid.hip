@@ -28,6 +28,7 @@ struct PyrArgs {
     int64_t stream_stride, slot_stride;
     int slot0, slot1;
     PyrGeom g;
+    int n_img, tiles_x, tiles_y;       // pyr_l0l1_kernel: XCD-aware 1-D launch when tiles_x > 0
 };
 
 __device__ __forceinline__ uint8_t* pyr_of(const PyrArgs& a, int img)
@@ -85,8 +86,19 @@ __global__ __launch_bounds__(256) void pyr_l0l1_kernel(PyrArgs a)
     const int w = a.g.w[0], h = a.g.h[0], pitch0 = a.g.pitch[0];
     const int w1 = a.g.w[1], h1 = a.g.h[1], pitch1 = a.g.pitch[1];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
-    const int img = blockIdx.z;
+    // workgroup -> (image, tile): with the 1-D launch all tiles of an image run on ONE XCD (round-robin dispatch over 8 XCDs, an
+    // L2 each): horizontally adjacent tiles share every 128-byte line a 752-byte image row lays across their boundary, and
+    // vertically adjacent ones their 4 halo rows -- on eight L2s each of those lines is fetched once per XCD that meets it
+    // (PMC: 2.3x the image bytes), on one L2 once.
+    int img, bx, by;
+    if (a.tiles_x > 0) {
+        const int L = blockIdx.x, j = L >> 3, per = a.tiles_x * a.tiles_y;
+        img = (L & 7) + 8 * (j / per);
+        if (img >= a.n_img) return;
+        const int t = j % per;
+        by = t / a.tiles_x; bx = t - by * a.tiles_x;
+    } else { img = blockIdx.z; bx = blockIdx.x; by = blockIdx.y; }
+    const int x0 = bx * FT_W, y0 = by * FT_H;
     const int s = img / a.imgs_per_stream, cam = img - s * a.imgs_per_stream;
     const uint8_t* in = (cam == 0 ? a.img0 : a.img1) + s * a.img_stride;
     uint8_t* base = pyr_of(a, img);
@@ -399,6 +411,7 @@ int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stri
     a.img0 = img0; a.img1 = img1; a.img_stride = img_stride; a.imgs_per_stream = imgs_per_stream;
     a.pyr_base = pyr_base; a.stream_stride = stream_stride; a.slot_stride = slot_stride;
     a.slot0 = slot0; a.slot1 = slot1; a.g = g;
+    a.n_img = 0; a.tiles_x = 0; a.tiles_y = 0;
     const int n_img = n_streams * imgs_per_stream;
     const int w = g.w[0], h = g.h[0];
     // the fused level-0 + level-1 kernel needs: dword-aligned rows, whole 32-row tiles, a last tile column that still holds the
@@ -407,7 +420,10 @@ int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stri
                        (img_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(img0) & 3) == 0 && (!img1 || (reinterpret_cast<uintptr_t>(img1) & 3) == 0) &&
                        !getenv("AV_PYR_UNFUSED");
     if (fused) {
-        dim3 grid((w + FT_W - 1) / FT_W, h / FT_H, n_img);
+        static const bool xcd_map = [] { const char* e = getenv("AV_PYR_XCD"); return !(e && atoi(e) == 0); }();      // A/B switch
+        const int tx = (w + FT_W - 1) / FT_W, ty = h / FT_H;
+        a.n_img = n_img; a.tiles_x = xcd_map ? tx : 0; a.tiles_y = ty;
+        dim3 grid = xcd_map ? dim3((unsigned)(tx * ty) * 8u * (unsigned)((n_img + 7) / 8)) : dim3(tx, ty, n_img);
         if (write_level0) hipLaunchKernelGGL(pyr_l0l1_kernel<true>, grid, dim3(256), 0, st, a);
         else { hipLaunchKernelGGL(pyr_l0l1_kernel<false>, grid, dim3(256), 0, st, a); if (wrote_level0) *wrote_level0 = false; }
         AV_LAUNCH_CHECK();

@@ -292,3 +292,20 @@ class BatchedMSCKF(object):
         o = (C.c_double * 8)()
         N.check(N.lib().av_msckf_batch_work(self._h, int(enable), C.byref(o)))
         return dict(zip(self.WORK_NAMES, [float(v) for v in o]))
+
+    def debug_capture(self, enable=True):
+        """Parity-test tap: keep gamma / delta_x / P+ of the two update phases of every stream's last step (tests only)."""
+        N.check(N.lib().av_msckf_batch_debug_capture(self._h, 1 if enable else 0))
+
+    def debug_read(self, s, phase, gamma_cap=8192):
+        """(gamma float64[k], rows, dx float64[n] or None, P_after float64[n,n] or None) of phase 0 (remove_lost_features) or
+        1 (prune_cam_state_buffer) of stream s's last step."""
+        ncap = 21 + 6 * (int(self.config.max_cam_state_size) + 1)
+        g = np.zeros(gamma_cap); dx = np.zeros(ncap); P = np.zeros(ncap * ncap)
+        ng, n, rows = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        N.check(N.lib().av_msckf_batch_debug_read(self._h, int(s), int(phase), g.ctypes.data_as(C.c_void_p), gamma_cap, C.byref(ng),
+                                                  dx.ctypes.data_as(C.c_void_p), P.ctypes.data_as(C.c_void_p), ncap, C.byref(n), C.byref(rows)))
+        k = int(n.value)
+        if rows.value <= 0:
+            return g[:ng.value].copy(), 0, None, None
+        return g[:ng.value].copy(), int(rows.value), dx[:k].copy(), P[:k * k].reshape(k, k).copy()
