@@ -630,7 +630,7 @@ def main():
                        'the reference-size thin QR (2mn^2 - 2/3 n^3, msckf.py:554) listed apart because the column-compressed update never runs it; '
                        'time: HIP events on every stream group\'s stream around the launches of each phase (triangulation .. covariance update), '
                        'summed over the %d groups, inside the timed region of the complete path (so it includes waiting for CUs the front-end holds)'
-                       % len(os.environ.get('AV_MSCKF_GROUPS', '4')),
+                       % int(os.environ.get('AV_MSCKF_GROUPS', '4' if S >= 256 else ('2' if S >= 64 else '1'))),
             }
         if world == 1 and not args.no_cpu_baseline:
             n_traj = (T0 + K) if with_msckf else 0

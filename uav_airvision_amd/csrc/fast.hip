@@ -136,11 +136,29 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
         mask4[it] = 0xFFFFFFFFu;
         if (mask_dw) mask4[it] = (x + 4 <= a.w && y < a.h) ? *reinterpret_cast<const uint32_t*>(a.mask + img_i * a.mask_stride + (size_t)y * a.w + x) : 0u;
     }
-    if (inside) {
-        for (int i = tid; i < PH * PWD; i += 256) {
+    // Tile rows as dwords whenever rows, stride and base are dword aligned (then a dword lies wholly inside or wholly outside the
+    // valid columns): all four loads of a thread are issued in one basic block -- as a loop the compiler waited for every load
+    // before issuing the next (one dword in flight per thread); rows above / below the valid rows are clamped, dwords left /
+    // right of the valid columns read as zero.  Pixels outside the image never reach a valid output (corners need x, y in
+    // [3, dim - 3)), so clamp vs reflect vs zero is immaterial.
+    const bool dw_rows = ((a.img_pitch | a.w | (int)(a.img_stride & 3) | (int)(reinterpret_cast<uintptr_t>(a.img) & 3)) & 3) == 0;
+    (void)inside;
+    if (dw_rows) {
+        constexpr int NLD = (PH * PWD + 255) / 256;
+        uint32_t v[NLD]; bool in[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int i = min(tid + 256 * it, PH * PWD - 1);
             const int r = i / PWD, c = i - r * PWD;
             const int xb = x0 - 4 + 4 * c;
-            pixw[i] = xb + 4 <= a.w + a.border ? *reinterpret_cast<const uint32_t*>(img + (ptrdiff_t)(y0 - 4 + r) * a.img_pitch + xb) : 0u;
+            const int y = min(max(y0 - 4 + r, -a.border), a.h + a.border - 1);
+            in[it] = xb >= -a.border && xb + 4 <= a.w + a.border;
+            v[it] = *reinterpret_cast<const uint32_t*>(in[it] ? img + (ptrdiff_t)y * a.img_pitch + xb : img);
+        }
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int i = tid + 256 * it;
+            if (i < PH * PWD) pixw[i] = in[it] ? v[it] : 0u;
         }
     } else {
         for (int i = tid; i < PH * PW; i += 256) {

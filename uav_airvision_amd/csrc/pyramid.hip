@@ -109,39 +109,64 @@ __global__ __launch_bounds__(256) void pyr_l0l1_kernel(PyrArgs a)
     // ---- stage rows y0-2 .. y0+FT_H+1, columns x0-4 .. x0+131 (reflect-101 outside the image): per row eight 16-byte chunks
     //      of the tile's own columns plus the two halo dwords ----
     const bool al16 = ((a.img_stride & 15) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
-    for (int i = tid; i < (FT_H + 4) * 10; i += 256) {
-        const int r = i / 10, j = i - r * 10;
-        const int gy = av_reflect101(y0 - 2 + r, h);
-        const uint8_t* row = in + (size_t)gy * w;
-        if (j < 8) {
-            const int gx = x0 + 16 * j;
-            uint32_t v[4];
-            if (gx + 16 <= w && al16) {
-                const uint4 q = *reinterpret_cast<const uint4*>(row + gx);
-                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-            } else {
+    // Two items per thread (360 items, 256 threads).  The loads of BOTH items are issued before either is waited for: as a plain
+    // loop the compiler waited (vmcnt(0)) inside every iteration, i.e. one 16-byte load in flight per thread -- 4 KB per workgroup,
+    // far below what HBM latency x bandwidth needs per CU once the level-0 store stream is gone.
+    {
+        uint4 q4[2]; uint32_t hv[2]; int kind[2], rr[2], jj[2];          // kind: 0 none, 1 sixteen bytes, 2 halo dword, 3 gather (image border)
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    if (gx + 4 * d + 4 <= w) v[d] = *reinterpret_cast<const uint32_t*>(row + gx + 4 * d);
-                    else {
-                        v[d] = 0;
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u;
+            const bool valid = i < (FT_H + 4) * 10;
+            const int r = valid ? i / 10 : 0, j = valid ? i - r * 10 : 0;
+            rr[u] = r; jj[u] = j;
+            kind[u] = valid ? 3 : 0; hv[u] = 0; q4[u] = make_uint4(0, 0, 0, 0);
+        }
+        if (al16) {                                      // wave-uniform; the four loads below sit in ONE basic block: no wait between them
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) { int x = av_reflect101(gx + 4 * d + b, w); x = min(max(x, 0), w - 1); v[d] |= (uint32_t)row[x] << (8 * b); }
+            for (int u = 0; u < 2; ++u) {
+                const int r = rr[u], j = jj[u];
+                const uint8_t* row = in + (size_t)av_reflect101(y0 - 2 + r, h) * w;
+                const int gx = x0 + 16 * j, gh = j == 8 ? x0 - 4 : x0 + FT_W;
+                const bool ok16 = kind[u] != 0 && j < 8 && gx + 16 <= w;
+                const bool okh = kind[u] != 0 && j >= 8 && gh >= 0 && gh + 4 <= w;
+                q4[u] = *reinterpret_cast<const uint4*>(ok16 ? row + gx : in);          // (a lane without a 16-byte item re-reads the image's first line)
+                hv[u] = *reinterpret_cast<const uint32_t*>(okh ? row + gh : in);
+                kind[u] = ok16 ? 1 : (okh ? 2 : kind[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = rr[u], j = jj[u];
+            if (kind[u] == 1) {
+                uint32_t* dst = srcw + r * (FT_LP / 4) + 1 + 4 * j;
+                dst[0] = q4[u].x; dst[1] = q4[u].y; dst[2] = q4[u].z; dst[3] = q4[u].w;
+            } else if (kind[u] == 2) {
+                srcw[r * (FT_LP / 4) + (j == 8 ? 0 : FT_LP / 4 - 1)] = hv[u];
+            } else if (kind[u] == 3) {
+                const uint8_t* row = in + (size_t)av_reflect101(y0 - 2 + r, h) * w;
+                if (j < 8) {
+                    const int gx = x0 + 16 * j;
+                    uint32_t v[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        if (gx + 4 * d + 4 <= w) v[d] = *reinterpret_cast<const uint32_t*>(row + gx + 4 * d);
+                        else {
+                            v[d] = 0;
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) { int x = av_reflect101(gx + 4 * d + b, w); x = min(max(x, 0), w - 1); v[d] |= (uint32_t)row[x] << (8 * b); }
+                        }
                     }
+                    uint32_t* dst = srcw + r * (FT_LP / 4) + 1 + 4 * j;
+                    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+                } else {
+                    const int gx = j == 8 ? x0 - 4 : x0 + FT_W;
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { int x = av_reflect101(gx + b, w); x = min(max(x, 0), w - 1); v |= (uint32_t)row[x] << (8 * b); }
+                    srcw[r * (FT_LP / 4) + (j == 8 ? 0 : FT_LP / 4 - 1)] = v;
                 }
             }
-            uint32_t* dst = srcw + r * (FT_LP / 4) + 1 + 4 * j;
-            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
-        } else {
-            const int gx = j == 8 ? x0 - 4 : x0 + FT_W;
-            uint32_t v;
-            if (gx >= 0 && gx + 4 <= w) v = *reinterpret_cast<const uint32_t*>(row + gx);
-            else {
-                v = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) { int x = av_reflect101(gx + b, w); x = min(max(x, 0), w - 1); v |= (uint32_t)row[x] << (8 * b); }
-            }
-            srcw[r * (FT_LP / 4) + (j == 8 ? 0 : FT_LP / 4 - 1)] = v;
         }
     }
     __syncthreads();
