@@ -76,8 +76,11 @@ __global__ __launch_bounds__(256) void pad_level0_kernel(PyrArgs a)
 // u16 sums, column filter, (sum + 128) >> 8) and writes it, plus the mirror images of those level-1 pixels that lie within
 // 16 pixels of the image border (the frame of level 1).  The separate pad and first pyrDown kernels read the image and
 // re-read the padded level 0 (0.8 MB per image through L2); here every input byte is read once.
-constexpr int FT_W = 128, FT_H = 32, FT_LP = FT_W + 8;        // LDS row: columns x0-4 .. x0+131
-template <bool WRITE_L0>
+constexpr int FT_W = 128, FT_LP = FT_W + 8;        // LDS row: columns x0-4 .. x0+131
+// tile height: 96 rows when the image height allows (1,000 sixteen-byte items per workgroup: four loads in flight per thread,
+// 2.1 % halo rows), else 32
+constexpr int FT_H_TALL = 96, FT_H_BASE = 32;
+template <bool WRITE_L0, int FT_H>
 __global__ __launch_bounds__(256) void pyr_l0l1_kernel(PyrArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t src[(FT_H + 4) * FT_LP];
@@ -109,13 +112,14 @@ __global__ __launch_bounds__(256) void pyr_l0l1_kernel(PyrArgs a)
     // ---- stage rows y0-2 .. y0+FT_H+1, columns x0-4 .. x0+131 (reflect-101 outside the image): per row eight 16-byte chunks
     //      of the tile's own columns plus the two halo dwords ----
     const bool al16 = ((a.img_stride & 15) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
-    // Two items per thread (360 items, 256 threads).  The loads of BOTH items are issued before either is waited for: as a plain
+    // NIT items per thread ((FT_H + 4) x 10 items, 256 threads).  The loads of ALL items are issued before any is waited for: as a plain
     // loop the compiler waited (vmcnt(0)) inside every iteration, i.e. one 16-byte load in flight per thread -- 4 KB per workgroup,
     // far below what HBM latency x bandwidth needs per CU once the level-0 store stream is gone.
     {
-        uint4 q4[2]; uint32_t hv[2]; int kind[2], rr[2], jj[2];          // kind: 0 none, 1 sixteen bytes, 2 halo dword, 3 gather (image border)
+        constexpr int NIT = ((FT_H + 4) * 10 + 255) / 256;
+        uint4 q4[NIT]; uint32_t hv[NIT]; int kind[NIT], rr[NIT], jj[NIT];          // kind: 0 none, 1 sixteen bytes, 2 halo dword, 3 gather (image border)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NIT; ++u) {
             const int i = tid + 256 * u;
             const bool valid = i < (FT_H + 4) * 10;
             const int r = valid ? i / 10 : 0, j = valid ? i - r * 10 : 0;
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256) void pyr_l0l1_kernel(PyrArgs a)
         }
         if (al16) {                                      // wave-uniform; the four loads below sit in ONE basic block: no wait between them
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NIT; ++u) {
                 const int r = rr[u], j = jj[u];
                 const uint8_t* row = in + (size_t)av_reflect101(y0 - 2 + r, h) * w;
                 const int gx = x0 + 16 * j, gh = j == 8 ? x0 - 4 : x0 + FT_W;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void pyr_l0l1_kernel(PyrArgs a)
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NIT; ++u) {
             const int r = rr[u], j = jj[u];
             if (kind[u] == 1) {
                 uint32_t* dst = srcw + r * (FT_LP / 4) + 1 + 4 * j;
@@ -226,8 +230,8 @@ __global__ __launch_bounds__(256) void pyr_l0l1_kernel(PyrArgs a)
     }
     __syncthreads();
     // column filter: thread t -> level-1 row yo = t / 16, columns 4 xq .. 4 xq + 3 of the tile
-    if (tid < (FT_H / 2) * (FT_W / 8)) {
-        const int yo = tid >> 4, xq = tid & 15;
+    for (int t_ = tid; t_ < (FT_H / 2) * (FT_W / 8); t_ += 256) {
+        const int yo = t_ >> 4, xq = t_ & 15;
         uint32_t out = 0;
         const uint16_t* c = hs + (2 * yo) * (FT_W / 2) + 4 * xq;
 #pragma unroll
@@ -441,6 +445,8 @@ int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stri
     const int w = g.w[0], h = g.h[0];
     // the fused level-0 + level-1 kernel needs: dword-aligned rows, whole 32-row tiles, a last tile column that still holds the
     // 17 pixels its frame mirrors, images large enough that a pixel is never in two mirror bands
+    static const bool tall_ok = [] { const char* e = getenv("AV_PYR_TALL"); return !(e && atoi(e) == 0); }();      // A/B switch
+    const int FT_H = (tall_ok && (h % FT_H_TALL) == 0 && h >= 2 * FT_H_TALL) ? FT_H_TALL : FT_H_BASE;
     const bool fused = g.levels >= 2 && (w & 15) == 0 && (h % FT_H) == 0 && h >= 64 && w >= 64 && (w % FT_W == 0 || w % FT_W >= 20) &&
                        (img_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(img0) & 3) == 0 && (!img1 || (reinterpret_cast<uintptr_t>(img1) & 3) == 0) &&
                        !getenv("AV_PYR_UNFUSED");
@@ -449,8 +455,13 @@ int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stri
         const int tx = (w + FT_W - 1) / FT_W, ty = h / FT_H;
         a.n_img = n_img; a.tiles_x = xcd_map ? tx : 0; a.tiles_y = ty;
         dim3 grid = xcd_map ? dim3((unsigned)(tx * ty) * 8u * (unsigned)((n_img + 7) / 8)) : dim3(tx, ty, n_img);
-        if (write_level0) hipLaunchKernelGGL(pyr_l0l1_kernel<true>, grid, dim3(256), 0, st, a);
-        else { hipLaunchKernelGGL(pyr_l0l1_kernel<false>, grid, dim3(256), 0, st, a); if (wrote_level0) *wrote_level0 = false; }
+        if (FT_H == FT_H_TALL) {
+            if (write_level0) hipLaunchKernelGGL((pyr_l0l1_kernel<true, FT_H_TALL>), grid, dim3(256), 0, st, a);
+            else { hipLaunchKernelGGL((pyr_l0l1_kernel<false, FT_H_TALL>), grid, dim3(256), 0, st, a); if (wrote_level0) *wrote_level0 = false; }
+        } else {
+            if (write_level0) hipLaunchKernelGGL((pyr_l0l1_kernel<true, FT_H_BASE>), grid, dim3(256), 0, st, a);
+            else { hipLaunchKernelGGL((pyr_l0l1_kernel<false, FT_H_BASE>), grid, dim3(256), 0, st, a); if (wrote_level0) *wrote_level0 = false; }
+        }
         AV_LAUNCH_CHECK();
     } else {
         int chunks = (g.pitch[0] >> 4) * (g.h[0] + 2 * AV_PYR_BORDER);
