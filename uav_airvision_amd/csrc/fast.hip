@@ -117,12 +117,7 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
     const int x0 = bx * TW, y0 = by * TH;
     const int tid = threadIdx.x;
 
-    // pixel tile: 56 rows x 72 bytes from (x0-4, y0-4).  Tiles whose rows lie inside the (padded) image copy dwords
-    // (x0 is a multiple of 64, so x0-4 is dword aligned when pitch and base are); dwords beyond the padded row are zero;
-    // the other tiles clamp per byte.  Pixels outside the image never reach a valid output (corners need x, y in
-    // [3, dim-3)), so clamp vs reflect vs zero is immaterial.
-    const bool inside = x0 - 4 >= -a.border && y0 - 4 >= -a.border && y0 - 4 + PH <= a.h + a.border &&
-                        ((a.img_pitch | (int)(a.img_stride & 3) | (int)(reinterpret_cast<uintptr_t>(a.img) & 3)) & 3) == 0;
+    // pixel tile: 56 rows x 72 bytes from (x0-4, y0-4) (x0 is a multiple of 64, so x0-4 is dword aligned when pitch and base are)
     uint32_t* pixw = reinterpret_cast<uint32_t*>(pix);
     // The mask bytes of the four pixels each lane will judge in phase 3 are fetched NOW, with the pixel tile: a mask read
     // behind the non-max suppression was a dependent HBM round trip in the middle of every tile.
@@ -142,7 +137,6 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
     // right of the valid columns read as zero.  Pixels outside the image never reach a valid output (corners need x, y in
     // [3, dim - 3)), so clamp vs reflect vs zero is immaterial.
     const bool dw_rows = ((a.img_pitch | a.w | (int)(a.img_stride & 3) | (int)(reinterpret_cast<uintptr_t>(a.img) & 3)) & 3) == 0;
-    (void)inside;
     if (dw_rows) {
         constexpr int NLD = (PH * PWD + 255) / 256;
         uint32_t v[NLD]; bool in[NLD];
