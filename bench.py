@@ -229,6 +229,130 @@ def dry_run(args):
     return 0
 
 
+def measure_regime(torch, dev, local_rank, name, grid, S_r, img0, img1, imu_steps, frame_ts, n_pre, n_steps, host=False, what=''):
+    """The complete path (front-end + batched filter, pipelined as in the headline) at a small batch: the first S_r streams of the
+    resident synthetic frames, own engine pair, n_pre un-timed frames into the steady state, then n_steps timed ones.
+    These are the batch sizes the BASELINE EuRoC configs have per GPU (configs[2]: 1 stream; configs[4]: 8 streams at 1,500
+    features; run.bat:4-12: 63 streams); the headline batch (thousands of replicas) is the throughput regime, these are the
+    latency-bound ones.  host=True: frames handed over as pageable host arrays (H2D inside the timed region)."""
+    from uav_airvision_amd.frontend import FrontendEngine
+    from uav_airvision_amd.msckf_ops import BatchedMSCKF
+    cfg_r = make_config(grid)
+    eng = FrontendEngine(cfg_r, n_streams=S_r, device=local_rank, inputs_persist=not host)
+    flt = BatchedMSCKF(cfg_r, S_r, device=local_rank, max_features=eng.max_features)
+    try:
+        imu_r = []
+        for k in range(n_pre + n_steps):
+            i, t, gy, ac = imu_steps[k]
+            m = i < S_r
+            imu_r.append((i[m], t[m], gy[m], ac[m]))
+        ts_r = [frame_ts[k][:S_r] for k in range(n_pre + n_steps)]
+        if host:
+            h0 = img0[:n_pre + n_steps, :S_r].cpu().numpy()
+            h1 = img1[:n_pre + n_steps, :S_r].cpu().numpy()
+            frames = lambda k: (h0[k], h1[k])
+        else:
+            frames = lambda k: (img0[k][:S_r], img1[k][:S_r])
+        path = CompletePath(torch, dev, eng, flt, torch.cuda.Stream(device=dev), frames, host, imu_r, imu_r, ts_r)
+        path.run_pipelined(0, n_pre)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        path.run_pipelined(n_pre, n_pre + n_steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        feats = eng.read_features()
+        c = flt.counters()
+        return dict(name=name, what=what, streams=S_r, grid='%dx%dx%d' % tuple(grid), features_per_frame=float(np.mean([len(f[0]) for f in feats])),
+                    steps=n_steps, prerolled_frames=n_pre, ms_per_step=1e3 * dt / n_steps, stream_frames_per_s=S_r * n_steps / dt,
+                    frames_per_s_per_stream=n_steps / dt, cam_states=[c['min_cam_states'], c['max_cam_states']],
+                    inputs='host numpy arrays, H2D inside the timed region (PCIe-inclusive)' if host else 'resident in HBM')
+    finally:
+        eng.close(); flt.close()
+
+
+class CompletePath(object):
+    """The complete path for one engine pair, organised like the reference's VIO (vio.py:24-76: image thread -> feature
+    queue -> filter thread): the calling thread drives the front-end and hands every frame's feature message to a filter
+    thread through a bounded queue, so the front-end of later frames overlaps the filter step of earlier ones.
+    frames(k) -> (cam0, cam1) of step k for all streams (cuda tensors, or host arrays with host=True); imu_fe / imu_flt: per
+    step (stream index, t, gyro, acc) arrays for the two consumers; frame_ts[k][s]."""
+
+    def __init__(self, torch, dev, eng, flt, filt_stream, frames, host, imu_fe, imu_flt, frame_ts):
+        self.torch, self.dev, self.eng, self.flt, self.filt_stream = torch, dev, eng, flt, filt_stream
+        self.frames, self.host, self.imu_fe, self.imu_flt, self.frame_ts = frames, host, imu_fe, imu_flt, frame_ts
+        self.msckf_s, self.push_s, self.poses = [0.0], [0.0], []      # poses: (frame index, out[S,12]) of every filter step
+        self.step_times = None
+
+    def run_fe(self, k):
+        i, t, gy, ac = self.imu_fe[k]
+        self.eng.push_imu_batch(i, t, gy)
+        a, b = self.frames(k)
+        if self.host:
+            self.eng.step_host(a, b, self.frame_ts[k])
+        else:
+            self.eng.step(a, b, self.frame_ts[k])
+
+    def run_filter(self, k, ids_h, uv_h, n_h, queued=False):
+        t1 = time.perf_counter()
+        i, t, gy, ac = self.imu_flt[k]
+        self.flt.push_imu(i, t, gy, ac)
+        self.push_s[0] += time.perf_counter() - t1
+        with self.torch.cuda.stream(self.filt_stream):         # the filter's kernels overlap the next frame's front-end kernels
+            if queued:
+                self.poses.append((k, self.flt.submit(ids_h, uv_h, n_h, self.frame_ts[k])))   # the stream groups run behind their own queues ...
+                self.flt.wait(1)                               # ... at most one frame ahead of the slowest group
+            else:
+                self.poses.append((k, self.flt.step(ids_h, uv_h, n_h, self.frame_ts[k])))
+        self.msckf_s[0] += time.perf_counter() - t1
+
+    def run_pipelined(self, k_begin, k_end):
+        """Frames [k_begin, k_end).  The region ends when the last filter step has returned."""
+        import queue, threading
+        q = queue.Queue(maxsize=2)
+        err = []
+        eng, torch, dev = self.eng, self.torch, self.dev
+
+        def filter_loop():
+            torch.cuda.set_device(dev)
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                try:
+                    if not err:
+                        self.run_filter(*item, queued=True)
+                except Exception as e:          # surfaced by the main thread after the join
+                    err.append(e)
+
+        th = threading.Thread(target=filter_loop, name='msckf')
+        th.start()
+        try:
+            # frame k+1 is enqueued before frame k's features are consumed: the read-back of k (pinned, double buffered)
+            # sits between the two steps on the stream, so the GPU never waits for this thread
+            self.run_fe(k_begin)
+            eng.read_features_begin(k_begin & 1)
+            for k in range(k_begin, k_end):
+                if k + 1 < k_end:
+                    self.run_fe(k + 1)
+                    eng.read_features_begin((k + 1) & 1)
+                ids_h, uv_h, n_h = eng.read_features_end(k & 1)      # waits for frame k's copy only; fresh host arrays
+                q.put((k, ids_h, uv_h, n_h))
+                if self.step_times is not None:
+                    self.step_times.append((k, time.perf_counter()))
+        finally:
+            q.put(None)
+            th.join()
+        if err:
+            raise err[0]
+        self.flt.wait(0)                                             # the last queued step retires inside the region
+
+    def run(self, k, filt=True):
+        self.run_fe(k)
+        if self.flt is not None and filt:
+            ids_h, uv_h, n_h = self.eng.read_features_raw()
+            self.run_filter(k, ids_h, uv_h, n_h)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -242,6 +366,7 @@ def main():
     ap.add_argument('--host-images', action='store_true', help='front-end only, images handed over as host numpy arrays every step '
                     '(av_frontend_step_host: the PCIe-inclusive rate quoted in DESIGN.md; never the contract value)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-regimes', action='store_true', help='skip the small-batch regime lines (S = 1, 8 x 1500 features, 64, host-fed)')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-budget', type=float, default=6.0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-seed', type=int, default=0, help=argparse.SUPPRESS)
@@ -393,10 +518,6 @@ def main():
     if with_msckf:
         from uav_airvision_amd.msckf_ops import BatchedMSCKF
         flt = BatchedMSCKF(cfg, S, device=local_rank, rows_cap=4096 if 5 * eng.max_features + 64 <= 4096 else None, max_features=eng.max_features)
-    msckf_s = [0.0]
-    push_s = [0.0]
-    poses0 = []                                  # (frame index, out[S,12]) of every filter step: stream 0's row is the GPU trajectory
-
     filt_stream = torch.cuda.Stream(device=dev) if flt is not None else None
 
     host0 = host1 = None
@@ -405,77 +526,12 @@ def main():
         del img0, img1
         torch.cuda.empty_cache()
 
-    def run_fe(k):
-        i, t, gy, ac = imu_steps[k]
-        eng.push_imu_batch(i, t, gy)
-        if host0 is not None:
-            eng.step_host(host0[k], host1[k], frame_ts[k])
-        else:
-            eng.step(img0[k], img1[k], frame_ts[k])
-
-    def run_filter(k, ids_h, uv_h, n_h, queued=False):
-        t1 = time.perf_counter()
-        i, t, gy, ac = imu_steps_f[k]
-        flt.push_imu(i, t, gy, ac)
-        push_s[0] += time.perf_counter() - t1
-        with torch.cuda.stream(filt_stream):         # the filter's kernels overlap the next frame's front-end kernels
-            if queued:
-                poses0.append((k, flt.submit(ids_h, uv_h, n_h, frame_ts[k])))   # the stream groups run behind their own queues ...
-                flt.wait(1)                                 # ... at most one frame ahead of the slowest group
-            else:
-                poses0.append((k, flt.step(ids_h, uv_h, n_h, frame_ts[k])))
-        msckf_s[0] += time.perf_counter() - t1
-
-    step_times = [] if os.environ.get('AV_BENCH_STEP_TIMES') else None     # diagnostic: wall time at which every frame's features were handed to the filter
-
-    def run_pipelined(k_begin, k_end):
-        """Full path for frames [k_begin, k_end), organised like the reference's VIO (vio.py:24-76: image thread ->
-        feature queue -> filter thread): this thread drives the front-end and hands every frame's feature message to a
-        filter thread through a bounded queue, so the front-end of later frames overlaps the (host-blocking) filter step
-        of earlier ones.  The region ends when the last filter step has returned."""
-        import queue, threading
-        q = queue.Queue(maxsize=2)
-        err = []
-
-        def filter_loop():
-            torch.cuda.set_device(dev)
-            while True:
-                item = q.get()
-                if item is None:
-                    return
-                try:
-                    if not err:
-                        run_filter(*item, queued=True)
-                except Exception as e:          # surfaced by the main thread after the join
-                    err.append(e)
-
-        th = threading.Thread(target=filter_loop, name='msckf')
-        th.start()
-        try:
-            # frame k+1 is enqueued before frame k's features are consumed: the read-back of k (pinned, double buffered)
-            # sits between the two steps on the stream, so the GPU never waits for this thread
-            run_fe(k_begin)
-            eng.read_features_begin(k_begin & 1)
-            for k in range(k_begin, k_end):
-                if k + 1 < k_end:
-                    run_fe(k + 1)
-                    eng.read_features_begin((k + 1) & 1)
-                ids_h, uv_h, n_h = eng.read_features_end(k & 1)      # waits for frame k's copy only; fresh host arrays
-                q.put((k, ids_h, uv_h, n_h))
-                if step_times is not None:
-                    step_times.append((k, time.perf_counter()))
-        finally:
-            q.put(None)
-            th.join()
-        if err:
-            raise err[0]
-        flt.wait(0)                                             # the last queued step retires inside the region
-
-    def run(k, filt=True):
-        run_fe(k)
-        if flt is not None and filt:
-            ids_h, uv_h, n_h = eng.read_features_raw()
-            run_filter(k, ids_h, uv_h, n_h)
+    path = CompletePath(torch, dev, eng, flt, filt_stream,
+                        (lambda k: (host0[k], host1[k])) if host0 is not None else (lambda k: (img0[k], img1[k])),
+                        host0 is not None, imu_steps, imu_steps_f, frame_ts)
+    path.step_times = [] if os.environ.get('AV_BENCH_STEP_TIMES') else None     # diagnostic: wall time at which every frame's features were handed to the filter
+    msckf_s, push_s, poses0, step_times = path.msckf_s, path.push_s, path.poses, path.step_times
+    run, run_pipelined = path.run, path.run_pipelined
 
     def barrier():
         if world > 1:
@@ -548,6 +604,21 @@ def main():
     # counter reduction is the only end-of-run exchange (no data-path collective)
     n_t, n_trk, n_cand, n_pub, n_match1, n_match2 = [float(v) / world for v in shard.sum_over_ranks([n_t, n_trk, n_cand, n_pub, n_match1, n_match2])]
 
+    # ---- the batch sizes the EuRoC configs really have (latency-bound regimes), same frames, own small engine pairs ----
+    regimes = None
+    if with_msckf and world == 1 and not args.no_regimes and tuple(args.grid) == (4, 5, 15):
+        n_pre_r = PREROLL_FULL + 1
+        n_st_r = max(1, min(20, F - n_pre_r))
+        regimes = []
+        for name, grid_r, S_r, host_r, what in (
+                ('single_stream', (4, 5, 15), 1, False, 'BASELINE configs[2] batch size: one sequence on one GPU (also configs[3] per GPU)'),
+                ('offset_sweep_share_8x1500', (10, 15, 10), min(8, S), False, 'BASELINE configs[4] per-GPU share: 8 streams at grid 10x15x10 = 1,500 features'),
+                ('run_bat_64', (4, 5, 15), min(64, S), False, 'run.bat:4-12 on one GPU: 9 sequences x 7 offsets = 63 streams'),
+                ('host_fed_128', (4, 5, 15), min(128, S), True, 'complete path with the frames handed over as host arrays every step (PCIe-inclusive; never the contract value)')):
+            try:
+                regimes.append(measure_regime(torch, dev, local_rank, name, grid_r, S_r, img0, img1, imu_steps, frame_ts, n_pre_r, n_st_r, host=host_r, what=what))
+            except Exception as e:          # a regime line must never take the headline down
+                regimes.append(dict(name=name, error=repr(e)))
     fps = world * S * K / elapsed
     b_frame, p_frame = frame_bytes(n_t, n_trk, n_match1 + n_match2)      # LK point passes actually run (lazy candidate matching)
     lk_ms, lk_n = timing['lk']
@@ -613,6 +684,8 @@ def main():
             'msckf_in_step': with_msckf, 'msckf_wall_ms_per_step': 1e3 * msckf_s[0] / K, 'msckf_push_imu_ms_per_step': 1e3 * push_s[0] / K,
             'frontend_only_frames_per_s': (world * S * K / fe_elapsed) if fe_elapsed else None,
         }
+        if regimes is not None:
+            out['regimes'] = regimes
         if w_t0 is not None:
             dw = {k: w_t1[k] - w_t0[k] for k in w_t1}
             fl = dw['gate_flops'] + dw['update_flops']

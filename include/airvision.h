@@ -28,6 +28,7 @@ extern "C" {
 #define AV_E_HIP        -2   /* a HIP runtime call failed (see av_last_error) */
 #define AV_E_CAPACITY   -3   /* a device-side capacity was exceeded (e.g. FAST corners > max_corners) */
 #define AV_E_NODEVICE   -4   /* no gfx950 device visible */
+#define AV_E_NUMERIC    -5   /* a factorisation met a non-positive or non-finite pivot (per-stream: that stream is stopped) */
 
 #define AV_MAX_LEVELS    5   /* pyramid levels 0..4 (the reference uses maxLevel = 3, config.py:34) */
 #define AV_PYR_BORDER   16   /* border (pixels) of every padded pyramid level; >= LK win + 1 */

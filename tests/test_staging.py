@@ -71,6 +71,42 @@ def test_png_decoder_other_flavours_and_errors(tmp_path):
         decode_batch([ok, bad], out)
     with pytest.raises(N.AirvisionError, match='cannot open'):
         decode_batch([str(tmp_path / 'missing.png'), ok], out)
+    # one flipped bit inside the compressed data: the chunk CRC catches it (cv2.imread of the reference returns None for such a file,
+    # dataset.py:110) -- never garbage pixels with status 0
+    raw = bytearray(open(ok, 'rb').read())
+    raw[len(raw) // 2] ^= 0x10
+    flip = str(tmp_path / 'flip.png'); open(flip, 'wb').write(bytes(raw))
+    with pytest.raises(N.AirvisionError, match='CRC|corrupt'):
+        decode_batch([flip, ok], out)
+    # the same image re-chunked into many small IDAT chunks (libpng writes 8 KB chunks; the stream's end marker and Adler-32 may
+    # land in a chunk of their own) still decodes, and losing that last chunk is detected as a truncated stream
+    import struct, zlib
+    src = open(ok, 'rb').read()
+    pos, idat, ihdr = 8, b'', None
+    while pos < len(src):
+        ln = int.from_bytes(src[pos:pos + 4], 'big')
+        if src[pos + 4:pos + 8] == b'IDAT':
+            idat += src[pos + 8:pos + 8 + ln]
+        elif src[pos + 4:pos + 8] == b'IHDR':
+            ihdr = src[pos + 8:pos + 8 + ln]
+        pos += 12 + ln
+
+    def chunk(t, d):
+        return struct.pack('>I', len(d)) + t + d + struct.pack('>I', zlib.crc32(t + d) & 0xFFFFFFFF)
+    body, tail = idat[:-4], idat[-4:]                                  # the Adler-32 trailer goes into a chunk of its own
+    parts = [body[i:i + 8192] for i in range(0, len(body), 8192)]
+    many = str(tmp_path / 'many.png')
+    open(many, 'wb').write(src[:8] + chunk(b'IHDR', ihdr) + b''.join(chunk(b'IDAT', q) for q in parts) + chunk(b'IDAT', tail) + chunk(b'IEND', b''))
+    decode_batch([many, ok], out)
+    assert np.array_equal(out[0], g)
+    cut = str(tmp_path / 'cut.png')
+    open(cut, 'wb').write(src[:8] + chunk(b'IHDR', ihdr) + b''.join(chunk(b'IDAT', q) for q in parts) + chunk(b'IEND', b''))
+    with pytest.raises(N.AirvisionError, match='corrupt|truncated'):
+        decode_batch([cut, ok], out)
+    # a 16-bit greyscale file is refused, not truncated to 8 bits
+    g16 = str(tmp_path / 'g16.png'); Image.fromarray((g.astype(np.uint16) << 8)).save(g16)
+    with pytest.raises(Exception, match='uint16|expected uint8'):
+        decode_batch([g16, ok], out)
     small = str(tmp_path / 'small.png'); Image.fromarray(g[:100, :100]).save(small)
     with pytest.raises(Exception):
         decode_batch([small, ok], out)                                  # wrong size: Pillow's result does not fit the slot

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'libairvision_hip.so')
 
 AV_MAX_LEVELS = 5
 AV_PYR_BORDER = 16
-AV_OK, AV_E_INVALID, AV_E_HIP, AV_E_CAPACITY, AV_E_NODEVICE = 0, -1, -2, -3, -4
+AV_OK, AV_E_INVALID, AV_E_HIP, AV_E_CAPACITY, AV_E_NODEVICE, AV_E_NUMERIC = 0, -1, -2, -3, -4, -5
 AV_FE_INPUTS_PERSIST = 1
 
 

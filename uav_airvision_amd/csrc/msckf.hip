@@ -1020,7 +1020,10 @@ struct UpdArgs {
     int mode;                                    // batched back end: 0 = Cholesky pipeline, 1 = information form (upd_info_kernel)
     int kdir;                                    // batched back end: > 0 = rows kept (no QR compression: the stacked rows come in chunks), 0 = upd_k(m, nc)
     int round;                                   // batched back end: chunk number of a sequential update (> 0: residual minus H dx so far, dx accumulates)
+    int* status;                                 // batched back end: the stream's entry of StackArgs::stacked (NULL: single filter); a factorisation that meets a
+                                                 // non-positive or non-finite pivot writes UPD_BAD_PIVOT there and turns the update into a no-op
 };
+constexpr int UPD_BAD_PIVOT = -2;
 
 constexpr int UT = 1024;
 
@@ -1725,9 +1728,14 @@ __global__ __launch_bounds__(256) void upd_s_kernel(const UpdArgs* __restrict__ 
 // grid: three barriers per EIGHT columns (the unblocked form pays one per column, and the barrier is most of a step at
 // these sizes).  L goes back to Sbuf (row-major) for the substitution kernel, which reads it through the scalar cache.
 constexpr int CNB = 8;
-// in-place blocked Cholesky of the packed lower triangle Lp (k x k) by a 256-thread workgroup; ends on a barrier
-__device__ __forceinline__ void chol_packed_lds(double* Lp, int k, int tid)
+// in-place blocked Cholesky of the packed lower triangle Lp (k x k) by a 256-thread workgroup; ends on a barrier.
+// Returns false (to every thread) if a pivot was not positive and finite -- the matrix was not positive definite to working
+// precision, or held a NaN / Inf; the factor is then meaningless (the bad pivot is replaced by 1 so that nothing traps) and
+// the caller must not use it.
+__device__ __forceinline__ bool chol_packed_lds(double* Lp, int k, int tid)
 {
+    __shared__ int chol_bad;
+    if (tid == 0) chol_bad = 0;
     auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
     for (int j0 = 0; j0 < k; j0 += CNB) {
         const int nb = min(CNB, k - j0), jb = j0 + nb;
@@ -1742,6 +1750,7 @@ __device__ __forceinline__ void chol_packed_lds(double* Lp, int k, int tid)
                 double d = A[j][j];
 #pragma unroll
                 for (int t = 0; t < j; ++t) d -= A[j][t] * A[j][t];
+                if (!(d > 0.0) || !(d < 1.79e308)) { if (j < nb) chol_bad = 1; d = 1.0; }
                 d = sqrt(d);
                 A[j][j] = d;
                 const double inv = 1.0 / d;
@@ -1788,6 +1797,7 @@ __device__ __forceinline__ void chol_packed_lds(double* Lp, int k, int tid)
         }
         __syncthreads();
     }
+    return chol_bad == 0;
 }
 __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict__ arr)
 {
@@ -1803,12 +1813,15 @@ __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict
         if (c <= r) at(r, c) = a.Sbuf[(size_t)r * a.ld + c];
     }
     __syncthreads();
-    chol_packed_lds(Lp, k, tid);
+    const bool ok = chol_packed_lds(Lp, k, tid);
+    if (!ok && tid == 0 && a.status) *a.status = UPD_BAD_PIVOT;      // S = H P H^T + s^2 I not positive definite: the covariance is corrupt
     // L is written as a symmetric matrix: the substitution kernel reads eight consecutive rows of one COLUMN of L per step,
-    // which the mirrored upper triangle holds contiguously (one 64-byte scalar load instead of eight)
+    // which the mirrored upper triangle holds contiguously (one 64-byte scalar load instead of eight).
+    // After a bad pivot L = 1e150 I is written instead: Y = L^-1 [T | r] ~ 0, so delta_x = 0 and P stays as it is (no NaN reaches
+    // the state); the host stops the stream on the flag.
     for (int e = tid; e < k * k; e += 256) {
         const int r = e / k, c = e - r * k;
-        a.Sbuf[(size_t)r * a.ld + c] = c <= r ? at(r, c) : at(c, r);
+        a.Sbuf[(size_t)r * a.ld + c] = ok ? (c <= r ? at(r, c) : at(c, r)) : (r == c ? 1e150 : 0.0);
     }
 }
 
@@ -2198,23 +2211,37 @@ __global__ __launch_bounds__(256) void upd_gram_chol_kernel(const UpdArgs* __res
     const int tid = threadIdx.x, m = a.m, nc = a.nc, k1 = nc + 1;
     const int nsl = (m + GRAM_CHUNK - 1) / GRAM_CHUNK;
     auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
+    __shared__ double dmax_s[4];
+    double dloc = 0.0;
     for (int e = tid; e < k1 * k1; e += 256) {
         const int r = e / k1, c = e - r * k1;
         if (c > r) continue;
         double v = 0;
         for (int y = 0; y < nsl; ++y) v += a.W[(size_t)y * k1 * k1 + (size_t)r * k1 + c];      // fixed order: deterministic
-        if (r == c) v = r < nc ? v + (1e-12 * v + 1e-300) : 2.0 * v + 1.0;                      // E on the diagonal; the border pivot only has to stay positive
+        if (r == c && r < nc) dloc = fmax(dloc, v);      // (a NaN on the diagonal is dropped by fmax here and caught by the pivot test below)
         at(r, c) = v;
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) dloc = fmax(dloc, __shfl_xor(dloc, d, 64));
+    if ((tid & 63) == 0) dmax_s[tid >> 6] = dloc;
     __syncthreads();
-    chol_packed_lds(Lp, k1, tid);
+    // E = 1e-12 max_i A_ii on every diagonal entry: relative to the LARGEST column, so a column that is (numerically) zero -- a camera
+    // whose block the stacked rows do not constrain -- still gets a pivot well above the rounding of the sums, instead of 1e-12 of
+    // its own rounding noise.  The border pivot (rho - f^T f = the squared residual the columns cannot explain) only has to stay positive.
+    const double eps = 1e-12 * fmax(fmax(dmax_s[0], dmax_s[1]), fmax(dmax_s[2], dmax_s[3])) + 1e-300;
+    for (int r = tid; r < k1; r += 256) at(r, r) = r < nc ? at(r, r) + eps : 2.0 * at(r, r) + 1.0;
+    __syncthreads();
+    const bool ok = chol_packed_lds(Lp, k1, tid);
+    if (!ok && tid == 0 && a.status) *a.status = UPD_BAD_PIVOT;
+    // a Gram matrix that is not positive definite to working precision (or not finite): [F | f] = 0 turns this stream's update into
+    // a no-op (S = s^2 I, delta_x = 0, P unchanged); the stream is stopped on the flag instead of publishing NaN poses
     const size_t ldt = a.ldt;
     for (int e = tid; e < nc * nc; e += 256) {           // W[q][row] = F[row][q] = L[q][row] (row <= q), the k = nc rows the back end reads
         const int q = e / nc, row = e - q * nc;
-        a.W[(size_t)q * ldt + row] = row <= q ? at(q, row) : 0.0;
+        a.W[(size_t)q * ldt + row] = (ok && row <= q) ? at(q, row) : 0.0;
     }
     double* rcol = a.W + (size_t)nc * ldt;
-    for (int row = tid; row < nc; row += 256) rcol[row] = at(nc, row);
+    for (int row = tid; row < nc; row += 256) rcol[row] = ok ? at(nc, row) : 0.0;
 }
 // ================================================================================================
 // Stacking decisions of remove_lost_features / prune_cam_state_buffer ON THE DEVICE (msckf.py:658-668, 759-763): which gated
@@ -2306,7 +2333,7 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
     if (lane == 0) a.stacked[s] = overflow || too_many || dead ? -1 : m;
     for (int r = lane; r < a.rounds; r += 64) {
         UpdArgs u = b;
-        u.mode = mode; u.round = r; u.kdir = 0; u.nc = nc; u.cols = a.cols + (size_t)s * a.cols_stride;
+        u.mode = mode; u.round = r; u.kdir = 0; u.nc = nc; u.cols = a.cols + (size_t)s * a.cols_stride; u.status = a.stacked + s;
         u.blk_row = a.blk_row + i0; u.blk_len = a.blk_len + i0; u.n_blk = nb; u.m = (too_many || overflow) ? 0 : m;
         if (u.m > 0 && mode == 0 && a.compress) {
             if (r > 0) u.m = 0;
@@ -2551,6 +2578,7 @@ AV_EXPORT int av_msckf_update(av_msckf* c, const int32_t* blk_row_dev, const int
     hipStream_t st = (hipStream_t)stream;
     if (total_rows == 0) { for (int i = 0; i < c->n; ++i) dx_host[i] = 0.0; return AV_OK; }
     UpdArgs a;
+    memset(&a, 0, sizeof(a));
     a.P = c->P; a.n = c->n; a.ld = c->ld; a.Hsrc = c->Hblk; a.rsrc = c->rblk; a.blk_row = blk_row_dev; a.blk_len = blk_len_dev; a.n_blk = n_blk;
     a.prof = nullptr;
     a.W = c->W; a.ldt = c->rows_cap; a.T = c->T; a.Kt = c->Kt; a.Pn = c->Pn; a.dx = c->dx; a.obs_noise = obs_noise; a.m = total_rows;

@@ -38,14 +38,18 @@ int decode_one(const char* path, int width, int height, uint8_t* out, char* why,
     memset(&zs, 0, sizeof(zs));
     if (inflateInit(&zs) != Z_OK) { snprintf(why, why_cap, "zlib init failed"); return 2; }
     const size_t pitch = (size_t)width + 1;                      // filter byte + one row of 8-bit grey samples
-    std::vector<uint8_t> raw(pitch * (size_t)height);
+    std::vector<uint8_t> raw(pitch * (size_t)height + 8);       // + slack: the stream's end marker and Adler-32 may sit in a later IDAT chunk, and
+                                                                // inflate must be able to go on (and must not be able to write more than the image)
     zs.next_out = raw.data(); zs.avail_out = (uInt)raw.size();
     int zrc = Z_OK;
+    bool crc_bad = false;
     while (pos + 12 <= file.size()) {
         const uint32_t len = be32(&file[pos]);
         const uint8_t* type = &file[pos + 4];
         if (pos + 12 + (size_t)len > file.size()) break;
         const uint8_t* data = &file[pos + 8];
+        // chunk CRC (PNG spec 5.3: over type + data): a bit flip in a frame must not decode to plausible pixels (cv2.imread returns None)
+        if ((!memcmp(type, "IHDR", 4) || !memcmp(type, "IDAT", 4)) && (uint32_t)crc32(crc32(0L, Z_NULL, 0), type, 4 + len) != be32(data + len)) { crc_bad = true; break; }
         if (!memcmp(type, "IHDR", 4)) {
             if (len < 13) break;
             const uint32_t w = be32(data), h = be32(data + 4);
@@ -66,9 +70,11 @@ int decode_one(const char* path, int width, int height, uint8_t* out, char* why,
         }
         pos += 12 + (size_t)len;
     }
-    const bool complete = have_hdr && zs.avail_out == 0 && (zrc == Z_OK || zrc == Z_STREAM_END);
+    // Z_STREAM_END: the deflate stream ended where it says it does and its Adler-32 matched (inflate checks it); a stream that merely
+    // filled the output buffer (Z_OK, avail_out == 0) may be truncated
+    const bool complete = have_hdr && !crc_bad && zs.total_out == pitch * (size_t)height && zrc == Z_STREAM_END;
     inflateEnd(&zs);
-    if (!complete) { snprintf(why, why_cap, "%s: corrupt or truncated PNG", path); return 2; }
+    if (!complete) { snprintf(why, why_cap, "%s: corrupt or truncated PNG%s", path, crc_bad ? " (chunk CRC mismatch)" : ""); return 2; }
     // un-filter (PNG spec 9.2; bpp = 1): row r of the image lands in out + r * width
     const uint8_t* prev = nullptr;
     for (int r = 0; r < height; ++r) {

@@ -24,7 +24,9 @@ def read_image(path):
         a = np.asarray(im)
     if a.ndim == 3:
         a = a[..., 0]
-    return np.ascontiguousarray(a, dtype=np.uint8)
+    if a.dtype != np.uint8:                      # cv2.imread(path, -1) of the reference would hand a uint16 array on: never truncate it silently
+        raise ValueError('%s: %s image, expected uint8 (8-bit greyscale camera frames)' % (path, a.dtype))
+    return np.ascontiguousarray(a)
 
 
 class EuRoCDataset(object):
@@ -124,7 +126,10 @@ def decode_batch(paths, out, threads=16):
     if rc == N.AV_E_CAPACITY:                 # some file is not 8-bit greyscale: that file alone goes through Pillow
         for k, i in enumerate(idx):
             if status[k] == 1:
-                dst[k] = read_image(paths[i])
+                im = np.asarray(read_image(paths[i]))
+                if im.dtype != np.uint8 or im.shape != (h, w):         # e.g. a 16-bit PNG: never truncated silently
+                    raise ValueError('%s: %s %s image, expected uint8 %s' % (paths[i], im.dtype, im.shape, (h, w)))
+                dst[k] = im
             elif status[k] != 0:
                 N.check(N.AV_E_INVALID)
     else:
@@ -137,13 +142,14 @@ class FrameStager(object):
     """Batch staging for sweeps (reference: the reader threads of streaming/dataset.py:93-158): the frames of
     step k+1 of all S streams are decoded on host threads while step k runs on the GPU.  `next()` returns
     (timestamps float64[S] (-1 = stream finished), img0 uint8[S,h,w], img1) of the next step, or None when every stream
-    is done; the arrays stay valid until the call after the next one (two buffers)."""
+    is done; the arrays stay valid until the call after the next one (three buffers: one being filled by the
+    loader thread, the one just returned, the one returned before it)."""
 
     def __init__(self, datasets, height, width, max_frames=None, threads=16):
         from concurrent.futures import ThreadPoolExecutor
         self.S = len(datasets)
         self.its = [iter(d.stereo_files) for d in datasets]
-        self.buf = [np.zeros((2, self.S, height, width), np.uint8) for _ in range(2)]      # [slot][camera][stream]
+        self.buf = [np.zeros((2, self.S, height, width), np.uint8) for _ in range(3)]      # [slot][camera][stream]
         self.max_frames, self.threads, self.k = max_frames, threads, 0
         self.pool = ThreadPoolExecutor(1)
         self.fut = self.pool.submit(self._load, 0)
@@ -155,7 +161,7 @@ class FrameStager(object):
         if all(e is None for e in ent):
             return None
         ts = np.array([-1.0 if e is None else e[0] for e in ent])
-        buf = self.buf[k & 1]
+        buf = self.buf[k % 3]
         both = [None if e is None else e[1] for e in ent] + [None if e is None else e[2] for e in ent]
         decode_batch(both, buf.reshape(2 * self.S, buf.shape[2], buf.shape[3]), self.threads)     # cam0 and cam1 of all streams in one threaded call
         for s, e in enumerate(ent):

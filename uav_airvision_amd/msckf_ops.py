@@ -283,7 +283,7 @@ class BatchedMSCKF(object):
         N.check(N.lib().av_msckf_batch_stream_status(self._h, int(s), C.byref(st), msg, 160))
         return int(st.value), msg.value.decode()
 
-    WORK_NAMES = ('gate_flops', 'update_flops', 'reference_qr_flops', 'features_gated', 'updates', 'rows_stacked', 'chain_ms')
+    WORK_NAMES = ('gate_flops', 'update_flops', 'reference_qr_flops', 'features_gated', 'updates', 'rows_stacked', 'chain_ms', 'chain_timings_dropped')
 
     def work(self, enable=-1):
         """Algorithmic fp64 flops of the gates / updates run so far and the device time of the phase chains
