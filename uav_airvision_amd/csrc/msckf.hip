@@ -104,6 +104,11 @@ struct TriArgs {
     int outer_max, inner_max;
     double* out_pos;             // [n_feat][3] world position
     int* out_valid;              // [n_feat]
+    // device-resident filter (msckf_dev.inc): the features to triangulate are list[0 .. *n_list_dev) (indices into the per-feature
+    // arrays above; the stream of feature f is f / fs_stride), the kernel strides over the list whatever its grid; a valid position
+    // is also stored in the stream's feature table (camera pruning: the feature lives on), slot f_mslot[f] of stream f / fs_stride
+    const int* list; const int* n_list_dev; int fs_stride;
+    const int* f_mslot; double* meta_pos; int* meta_init; int meta_stride;
 };
 
 __device__ __forceinline__ void solve3(const double A[9], const double b[3], double x[3])
@@ -131,12 +136,8 @@ __device__ __forceinline__ void solve3(const double A[9], const double b[3], dou
     x[0] = (M[0][3] - M[0][1] * x[1] - M[0][2] * x[2]) / M[0][0];
 }
 
-__global__ __launch_bounds__(256) void triangulate_kernel(TriArgs a)
+__device__ __forceinline__ void triangulate_one(const TriArgs& a, int f, int lane)
 {
-    AV_FILTER_PRIO();
-    const int lane = threadIdx.x & 63;
-    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (f >= a.n_feat) return;
     const int o0 = a.obs_off[f], M = a.obs_off[f + 1] - o0;
     const int nv = 2 * M;                                   // views; host guarantees nv <= 64
     const bool act = lane < nv;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void triangulate_kernel(TriArgs a)
     // pose of this view (camera -> world), feature_position_initializer.py:19-26
     double Rv[9], tv[3], z[2] = {0, 0};
     {
-        const int ci = a.obs_cam[o0 + j] + (a.feat_stream ? a.feat_stream[f] * a.cam_stride : 0);
+        const int ci = a.obs_cam[o0 + j] + (a.feat_stream ? a.feat_stream[f] * a.cam_stride : (a.fs_stride > 0 ? (f / a.fs_stride) * a.cam_stride : 0));
         double Rwc[9];
         quat_to_rot(a.cam_q + 4 * ci, Rwc);                 // world -> cam0
         double R0[9];                                       // cam0 -> world = Rwc^T
@@ -270,10 +271,30 @@ __global__ __launch_bounds__(256) void triangulate_kernel(TriArgs a)
     unsigned long long bad = __ballot(act && !(depth_v > 0));
     if (lane == 0) {
         // position in the world: T_c0_w.R @ pf + T_c0_w.t (this lane is view 0, so Rv/tv = T_c0_w)
+        double pw[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) a.out_pos[3 * f + r] = Rv[r * 3 + 0] * pf[0] + Rv[r * 3 + 1] * pf[1] + Rv[r * 3 + 2] * pf[2] + tv[r];
-        a.out_valid[f] = bad == 0ull ? 1 : 0;
+        for (int r = 0; r < 3; ++r) { pw[r] = Rv[r * 3 + 0] * pf[0] + Rv[r * 3 + 1] * pf[1] + Rv[r * 3 + 2] * pf[2] + tv[r]; a.out_pos[3 * f + r] = pw[r]; }
+        const int ok = bad == 0ull ? 1 : 0;
+        a.out_valid[f] = ok;
+        if (a.meta_pos) {                                   // feature_position_initializer.py:72-76: position and is_initialized of the Feature
+            const size_t ms = (size_t)(f / a.fs_stride) * a.meta_stride + a.f_mslot[f];
+            a.meta_pos[3 * ms] = pw[0]; a.meta_pos[3 * ms + 1] = pw[1]; a.meta_pos[3 * ms + 2] = pw[2];
+            a.meta_init[ms] = ok;
+        }
     }
+}
+__global__ __launch_bounds__(256) void triangulate_kernel(TriArgs a)
+{
+    AV_FILTER_PRIO();
+    const int lane = threadIdx.x & 63;
+    if (a.list) {                                           // wave-uniform loop: a wavefront per listed feature
+        const int n = *a.n_list_dev;
+        for (int t = blockIdx.x * 4 + (threadIdx.x >> 6); t < n; t += gridDim.x * 4) triangulate_one(a, a.list[t], lane);
+        return;
+    }
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= a.n_feat) return;
+    triangulate_one(a, f, lane);
 }
 
 // ================================================================================================
@@ -310,6 +331,9 @@ struct FeatArgs {
     // triangulation failed is not evaluated and reads pass = 0 (msckf.py:646-656, 749-757: it is dropped before the Jacobian)
     const int* tri_idx;                  // [n_feat] index into tri_pos / tri_valid, or -1 = position known (`pos`); NULL = none
     const double* tri_pos; const int* tri_valid;
+    // device-resident filter (msckf_dev.inc): teams stride over feat_list[0 .. *n_list_dev) whatever the grid; valid[f] = 0 marks a
+    // feature without a usable position (triangulation or check_motion failed: not evaluated, pass = 0); stream of f = f / fs_stride
+    const int* n_list_dev; const int* valid; int fs_stride;
 };
 
 // dynamic LDS of feature_kernel for tracks of at most Mx observations (layout at the top of the kernel)
@@ -333,16 +357,30 @@ __device__ __forceinline__ void team_sync()
 }
 
 template <int TEAM>
+__device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, double* sm_all);
+
+template <int TEAM>
 __device__ __forceinline__ void feature_body(const FeatArgs& a)
 {
     AV_FILTER_PRIO();
     extern __shared__ double sm_all[];
-    const int slot = TEAM == 256 ? (int)blockIdx.x : (int)(blockIdx.x * (256 / TEAM) + threadIdx.x / TEAM);
-    if (slot >= a.n_list) return;                         // whole team
+    const int slot0 = TEAM == 256 ? (int)blockIdx.x : (int)(blockIdx.x * (256 / TEAM) + threadIdx.x / TEAM);
+    if (a.n_list_dev) {                                   // device-side count: every team strides over the list (team-uniform trip count)
+        const int n = *a.n_list_dev, stride = (int)gridDim.x * (256 / TEAM);
+        for (int slot = slot0; slot < n; slot += stride) { feature_one<TEAM>(a, slot, sm_all); team_sync<TEAM>(); }
+        return;
+    }
+    if (slot0 >= a.n_list) return;                        // whole team
+    feature_one<TEAM>(a, slot0, sm_all);
+}
+
+template <int TEAM>
+__device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, double* sm_all)
+{
     const int tid = threadIdx.x % TEAM;
     double* sm = sm_all + (TEAM == 256 ? 0 : (threadIdx.x / TEAM) * a.team_doubles);
     const int f = a.feat_list ? a.feat_list[slot] : slot;
-    const int sidx = a.feat_stream ? a.feat_stream[f] : 0;
+    const int sidx = a.feat_stream ? a.feat_stream[f] : (a.fs_stride > 0 ? f / a.fs_stride : 0);
     const int cam0 = sidx * a.cam_stride;
     const double* Pm = a.P + sidx * a.p_stride;
     double* Hout = a.Hout + sidx * a.h_stride;
@@ -352,7 +390,7 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
     const int R4 = 4 * M, C6 = 6 * M, K = R4 - 3;
     const int Mx = a.Mmax;
     const int tri = a.tri_idx ? a.tri_idx[f] : -1;
-    if (tri == -2 || (tri >= 0 && !a.tri_valid[tri])) {   // -2: failed check_motion on the host                  // whole team (uniform in f): triangulation failed, nothing to gate
+    if (tri == -2 || (tri >= 0 && !a.tri_valid[tri]) || (a.valid && !a.valid[f])) {   // -2: failed check_motion on the host                  // whole team (uniform in f): triangulation failed, nothing to gate
         if (tid == 0) { a.gamma[f] = 0.0; a.pass[f] = 0; }
         return;
     }
@@ -2139,10 +2177,17 @@ __global__ __launch_bounds__(256) void upd_gather_kernel(const UpdArgs* __restri
 constexpr int GRAM_CHUNK = 256;
 __device__ __forceinline__ bool upd_front_needed(const UpdArgs& a) { return a.m > 0 && a.mode == 0 && a.kdir <= 0 && upd_compress(a.m, a.nc); }
 
-__global__ __launch_bounds__(256) void upd_rowmap_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list)
+// (n_list_dev != NULL: the list was written on the device -- upd_stack_kernel -- and holds *n_list_dev streams; the workgroups
+//  stride over it.  NULL: one workgroup per listed stream, as launched by the host.)
+__device__ __forceinline__ void upd_rowmap_one(const UpdArgs& a);
+__global__ __launch_bounds__(256) void upd_rowmap_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list, const int* __restrict__ n_list_dev)
 {
     AV_FILTER_PRIO();
-    const UpdArgs a = arr[list[blockIdx.x]];
+    if (n_list_dev) { const int n = *n_list_dev; for (int l = blockIdx.x; l < n; l += gridDim.x) { upd_rowmap_one(arr[list[l]]); __syncthreads(); } return; }
+    upd_rowmap_one(arr[list[blockIdx.x]]);
+}
+__device__ __forceinline__ void upd_rowmap_one(const UpdArgs& a)
+{
     if (!upd_front_needed(a)) return;
     __shared__ int wsum[4], carry;
     int* srcrow = reinterpret_cast<int*>(a.Kt);
@@ -2168,10 +2213,15 @@ __global__ __launch_bounds__(256) void upd_rowmap_kernel(const UpdArgs* __restri
 }
 
 // slab (chunk y) of the Gram matrix of G = [Hc | r] (m x (nc + 1)): tile x of the lower 64 x 64 tiles
-__global__ __launch_bounds__(256) void upd_gram_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list)
+__device__ __forceinline__ void upd_gram_one(const UpdArgs& a);
+__global__ __launch_bounds__(256) void upd_gram_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list, const int* __restrict__ n_list_dev)
 {
     AV_FILTER_PRIO();
-    const UpdArgs a = arr[list[blockIdx.z]];
+    if (n_list_dev) { const int n = *n_list_dev; for (int l = blockIdx.z; l < n; l += gridDim.z) { upd_gram_one(arr[list[l]]); __syncthreads(); } return; }
+    upd_gram_one(arr[list[blockIdx.z]]);
+}
+__device__ __forceinline__ void upd_gram_one(const UpdArgs& a)
+{
     if (!upd_front_needed(a)) return;
     const int m = a.m, nc = a.nc, k1 = nc + 1;
     const int row0 = blockIdx.y * GRAM_CHUNK;
@@ -2202,11 +2252,16 @@ __global__ __launch_bounds__(256) void upd_gram_kernel(const UpdArgs* __restrict
         }
 }
 
-__global__ __launch_bounds__(256) void upd_gram_chol_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list)
+__device__ __forceinline__ void upd_gram_chol_one(const UpdArgs& a, double* Lp);
+__global__ __launch_bounds__(256) void upd_gram_chol_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list, const int* __restrict__ n_list_dev)
 {
     AV_FILTER_PRIO();
-    extern __shared__ double Lp[];
-    const UpdArgs a = arr[list[blockIdx.x]];
+    extern __shared__ double Lp_dyn[];
+    if (n_list_dev) { const int n = *n_list_dev; for (int l = blockIdx.x; l < n; l += gridDim.x) { upd_gram_chol_one(arr[list[l]], Lp_dyn); __syncthreads(); } return; }
+    upd_gram_chol_one(arr[list[blockIdx.x]], Lp_dyn);
+}
+__device__ __forceinline__ void upd_gram_chol_one(const UpdArgs& a, double* Lp)
+{
     if (!upd_front_needed(a)) return;
     const int tid = threadIdx.x, m = a.m, nc = a.nc, k1 = nc + 1;
     const int nsl = (m + GRAM_CHUNK - 1) / GRAM_CHUNK;
@@ -2263,6 +2318,14 @@ struct StackArgs {
     int S, rounds, cut1500, kch;
     int compress;                    // 1: a stream with more than kch rows is QR-compressed (update_front_batch_kernel) and updated in ONE round
     int* stacked;                    // out [S]: rows stacked (0 = no update), -1 = more chunks than `rounds` (nothing is updated)
+    // ---- device-resident filter (msckf_dev.inc); all NULL / 0 on the host-driven path ------------------------------------------
+    const int* n_cand; int fs_stride;        // rbeg == NULL: the features of stream s are [s * fs_stride, s * fs_stride + n_cand[s])
+    const int* stream_n;                     // state dimension of every stream (overrides base[s].n: the host does not know it)
+    const int* valid;                        // [n_feat] 0 = the feature was never evaluated (no position); work counters only
+    const int* over;                         // [S] 1: the stream's candidates reserved more rows than the block buffer holds, so they were
+    int* row_off_w; int* again_list; int* again_count;   //  gated without storage (row_off = -1): the stacked ones get compact offsets here and are listed to run again
+    int* clist; int* clist_count;            // out: streams whose stacked rows exceed one back-end pass (compression kernels stride over this list)
+    double* work;                            // [S][8] accumulators of av_msckf_batch_work: gate flops, update flops, reference-QR flops, gated, updates, rows
 };
 __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
 {
@@ -2271,7 +2334,21 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
     __shared__ int s_chunk[64];                          // first block of chunk c (c < rounds <= 63), then the end
     __shared__ int s_nch;
     const int s = blockIdx.x, lane = threadIdx.x;
-    const int i0 = a.rbeg[s], i1 = a.rbeg[s + 1];
+    const int i0 = a.rbeg ? a.rbeg[s] : s * a.fs_stride, i1 = a.rbeg ? a.rbeg[s + 1] : i0 + a.n_cand[s];
+    const bool two_pass = a.over && a.over[s];
+    const int n_state = a.stream_n ? a.stream_n[s] : a.base[s].n;
+    if (a.work) {        // per gated feature with r = 4M-3 rows against n columns  2 r n^2 + 2 r^2 n + r^3 / 3
+        double fl = 0; int cnt = 0;
+        for (int i = i0 + lane; i < i1; i += 64) {
+            if (a.valid && !a.valid[i]) continue;
+            const double r = 4.0 * (a.obs_off[i + 1] - a.obs_off[i]) - 3.0, n = (double)n_state;
+            fl += 2 * r * n * n + 2 * r * r * n + r * r * r / 3.0; ++cnt;
+        }
+        fl = wave_sum_f64(fl);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+        if (lane == 0) { a.work[8 * s] += fl; a.work[8 * s + 3] += (double)cnt; }
+    }
     int stacked = 0, nb = 0;
     unsigned long long used = 0ull;
     bool overflow = false;
@@ -2290,7 +2367,12 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
         const int pos = nb + __popcll(mask & ((1ull << lane) - 1ull));
         if (take) {
             if (pos < STACK_LDS_BLOCKS) s_len[pos] = rows; else overflow = true;
-            a.blk_row[i0 + pos] = a.row_off[i]; a.blk_len[i0 + pos] = rows;
+            int ro = a.row_off[i];
+            if (two_pass) {      // every passing feature up to the cut is stacked, so the rows stacked before this one are its compact offset
+                ro = before; a.row_off_w[i] = ro;
+                a.again_list[atomicAdd(a.again_count, 1)] = i;
+            }
+            a.blk_row[i0 + pos] = ro; a.blk_len[i0 + pos] = rows;
             for (int q = 0; q < nobs; ++q) used |= 1ull << a.obs_cam[o0 + q];
         }
         nb += __popcll(mask);
@@ -2303,7 +2385,8 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { used |= __shfl_xor(used, d, 64); }
     overflow = __ballot(overflow) != 0ull;
-    const UpdArgs b = a.base[s];
+    UpdArgs b = a.base[s];
+    b.n = n_state;
     const int nc = 6 * __popcll(used);
     const bool dead = b.mode == 2;                      // stopped by the host (msckf_batch.inc: b_fail_stream): no update, stacked = -1
     const int m = (overflow || dead) ? 0 : stacked;
@@ -2330,7 +2413,17 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
     __syncthreads();
     const int nch = s_nch;
     const bool too_many = nch > a.rounds || nch > 62;
-    if (lane == 0) a.stacked[s] = overflow || too_many || dead ? -1 : m;
+    if (lane == 0) {
+        a.stacked[s] = overflow || too_many || dead ? -1 : m;
+        const bool upd = m > 0 && !too_many;
+        if (upd && a.clist && mode == 0 && a.compress && m > a.kch) a.clist[atomicAdd(a.clist_count, 1)] = s;
+        if (upd && a.work) {     // per update of m stacked rows with k = min(m, n) rows kept, the reference's thin QR counted apart
+            const double mm = m, n = (double)n_state, k = mm < n ? mm : n;
+            a.work[8 * s + 1] += 2 * k * n * n + 2 * k * k * n + k * k * k / 3.0 + 2 * k * k * n + 4 * k * n * n;
+            if (mm > n) a.work[8 * s + 2] += 2 * mm * n * n - 2.0 / 3.0 * n * n * n;
+            a.work[8 * s + 4] += 1.0; a.work[8 * s + 5] += mm;
+        }
+    }
     for (int r = lane; r < a.rounds; r += 64) {
         UpdArgs u = b;
         u.mode = mode; u.round = r; u.kdir = 0; u.nc = nc; u.cols = a.cols + (size_t)s * a.cols_stride; u.status = a.stacked + s;
@@ -2531,7 +2624,7 @@ AV_EXPORT int av_msckf_triangulate(av_msckf* c, int n_feat, const int32_t* obs_o
     }
     if (max_views > 64) { av_set_error("av_msckf_triangulate: %d views per feature exceed one wavefront (64)", max_views); return AV_E_CAPACITY; }
     if (n_feat == 0) return AV_OK;
-    TriArgs a;
+    TriArgs a; memset(&a, 0, sizeof(a));
     a.n_feat = n_feat; a.obs_off = obs_off_dev; a.obs_cam = obs_cam_dev; a.obs_z = obs_z_dev; a.cam_q = cam_q_dev; a.cam_p = cam_p_dev;
     a.feat_stream = nullptr; a.cam_stride = 0;
     for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) a.R01[r * 3 + cc] = T_cam0_cam1_rowmajor44[r * 4 + cc]; a.t01[r] = T_cam0_cam1_rowmajor44[r * 4 + 3]; }
@@ -2558,7 +2651,7 @@ AV_EXPORT int av_msckf_feature_blocks(av_msckf* c, int n_feat, int n_cam, int ma
     if (total_rows > c->rows_cap) { av_set_error("av_msckf_feature_blocks: %d stacked rows exceed rows_cap %d", total_rows, c->rows_cap); return AV_E_CAPACITY; }
     if (max_obs < 2 || max_obs > c->max_cam + 1) { av_set_error("av_msckf_feature_blocks: max_obs %d out of range", max_obs); return AV_E_INVALID; }
     if (n_feat == 0) return AV_OK;
-    FeatArgs a;
+    FeatArgs a; memset(&a, 0, sizeof(a));
     a.n_feat = n_feat; a.n_cam = n_cam; a.ld = c->ld;
     a.obs_off = obs_off_dev; a.obs_cam = obs_cam_dev; a.obs_z = obs_z_dev; a.pos = pos_dev; a.dof = dof_dev; a.row_off = row_off_dev;
     a.cam_q = cam_q_dev; a.cam_p = cam_p_dev; a.cam_qn = cam_qn_dev; a.cam_pn = cam_pn_dev; a.P = c->P; a.chi2 = c->chi2;
