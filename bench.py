@@ -307,6 +307,8 @@ class CompletePath(object):
 
     def run_pipelined(self, k_begin, k_end):
         """Frames [k_begin, k_end).  The region ends when the last filter step has returned."""
+        if self.flt.device_resident():
+            return self.run_device_handover(k_begin, k_end)
         import queue, threading
         q = queue.Queue(maxsize=2)
         err = []
@@ -345,6 +347,27 @@ class CompletePath(object):
         if err:
             raise err[0]
         self.flt.wait(0)                                             # the last queued step retires inside the region
+
+    def run_device_handover(self, k_begin, k_end):
+        """The same path with the filter state resident on the device: the filter reads every frame's feature message where
+        the front-end left it (av_msckf_batch_submit_dev), so this thread only enqueues -- front-end step k, IMU samples, filter
+        step k -- and never waits for a result inside the loop; the library's stream groups work through their queues at most
+        two steps behind (vio.py:46-51 with the feature queue on the device)."""
+        from uav_airvision_amd import _native as N
+        torch = self.torch
+        for k in range(k_begin, k_end):
+            self.run_fe(k)
+            t1 = time.perf_counter()
+            i, t, gy, ac = self.imu_flt[k]
+            self.flt.push_imu(i, t, gy, ac)
+            self.push_s[0] += time.perf_counter() - t1
+            ms = N.current_stream()
+            with torch.cuda.stream(self.filt_stream):
+                self.poses.append((k, self.flt.submit_dev(self.eng, np.asarray(self.frame_ts[k], dtype=np.float64), msg_stream=ms)))
+            self.msckf_s[0] += time.perf_counter() - t1
+            if self.step_times is not None:
+                self.step_times.append((k, time.perf_counter()))
+        self.flt.wait(0)
 
     def run(self, k, filt=True):
         self.run_fe(k)

@@ -182,6 +182,11 @@ int av_frontend_read_features(av_frontend* fe, int64_t* ids_out, double* uv_out,
  * av_frontend_step between the two overlaps it with the consumption of this frame's features. */
 int av_frontend_read_features_begin(av_frontend* fe, int slot, void* stream);
 int av_frontend_read_features_end(av_frontend* fe, int slot, int64_t* ids_out, double* uv_out, int32_t* n_out, int cap);
+/* The same feature_msg where the last step left it, ON THE DEVICE: ids int64[S][cap], uv double[S][cap][4], n int32[S] with
+ * cap = av_frontend_max_features.  The buffers are rewritten by the next av_frontend_step; consume them with work enqueued on the
+ * stream the step ran on (av_msckf_batch_submit_dev copies them there).  This is the hand-over of pipeline.py:131-143 ->
+ * modules/vio.py:34-36,46-51 (feature_queue) without the host in between. */
+int av_frontend_features_dev(av_frontend* fe, const int64_t** ids_dev, const double** uv_dev, const int32_t** n_dev, int* cap);
 
 /* Pipeline state visible to callers (pipeline.py:33-40): the grid of the frame just published
  * (= prev_features after the callback returns).  Per feature k of stream `stream`:
@@ -290,8 +295,11 @@ int  av_msckf_batch_push_imu(av_msckf_batch* b, const int32_t* stream_idx, const
  * step" (sequences of different lengths stepped together): the stream idles and reports published = 0.
  * The first step fixes the message capacity `cap` the device buffers are sized for; rows_cap must be >= 5*cap
  * (camera-pruning update) and >= 1664 (lost-feature update: 1500-row cut + one block), else AV_E_CAPACITY;
- * rows_cap = 0 at create sizes the block buffers from that first `cap` (max(2048, 5*cap + 64) rows): the FIRST step's cap is
- * binding -- a later step with a larger cap fails with AV_E_CAPACITY unless rows_cap was given explicitly.
+ * rows_cap = 0 at create sizes the block buffers from that first `cap` (max(2048, 5*cap + 64) rows).  A later step with a larger
+ * cap REBUILDS them (and the device-resident observation store) for the wider message: the batch is drained and the device
+ * synchronised, the capacity grows geometrically (x1.5 at least) and the outgrown allocations stay parked until destroy -- pass
+ * the largest cap at the first step (BatchedMSCKF(max_features=...)) when the width of the messages varies.  An explicit
+ * rows_cap is never grown: a wider message than it can hold fails with AV_E_CAPACITY.
  * max_cam_states <= 24 (one back-end pass holds 144 columns = 6 per camera state); the reference's value is 20. */
 int  av_msckf_batch_step(av_msckf_batch* b, const int64_t* ids, const double* uv, const int32_t* n_feat, int cap,
                          const double* timestamps, double* out, void* stream);
@@ -305,6 +313,15 @@ int  av_msckf_batch_step(av_msckf_batch* b, const int64_t* ids, const double* uv
 int  av_msckf_batch_submit(av_msckf_batch* b, const int64_t* ids, const double* uv, const int32_t* n_feat, int cap,
                            const double* timestamps, double* out, void* stream);
 int  av_msckf_batch_wait(av_msckf_batch* b, int max_pending);
+/* av_msckf_batch_submit with the feature message in DEVICE arrays (av_frontend_features_dev): the three arrays are consumed by
+ * copies enqueued on msg_stream -- the stream that produced them -- before the call returns, so the producer may overwrite them
+ * at once; the filter's kernels run on the stream groups' own streams (a batch of one group: on `stream`) behind an event.
+ * timestamps and out are host arrays and must stay valid until av_msckf_batch_wait has let the step retire.  Blocks while
+ * more than two earlier steps are unfinished.  Needs the device-resident filter state (the default; AV_E_INVALID under
+ * AV_MSCKF_STORE=host). */
+int  av_msckf_batch_device_resident(const av_msckf_batch* b);     /* 1: state + observation map on the device (default), 0: host bookkeeping */
+int  av_msckf_batch_submit_dev(av_msckf_batch* b, const int64_t* ids_dev, const double* uv_dev, const int32_t* n_feat_dev, int cap,
+                               const double* timestamps, double* out, void* msg_stream, void* stream);
 int  av_msckf_batch_get_cov(av_msckf_batch* b, int stream_idx, double* P_host, int n, void* stream);
 int  av_msckf_batch_sizes(av_msckf_batch* b, int stream_idx, int32_t out3[3]);     /* [state dim, camera states, map features] */
 /* Full host-side state of one stream -- every target of measurement_update's injection (msckf.py:568-595), for parity tests

@@ -67,6 +67,7 @@ SIGNATURES = {
     'av_frontend_max_features': (C.c_int, [_P]),
     'av_frontend_read_features': (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
     'av_frontend_read_features_begin': (C.c_int, [_P, C.c_int, _P]),
+    'av_frontend_features_dev': (C.c_int, [_P, _P, _P, _P, _P]),
     'av_frontend_read_features_end': (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int]),
     'av_frontend_read_grid': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64), _P]),
     'av_frontend_read_counters': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32 * 8), _P]),
@@ -89,6 +90,8 @@ SIGNATURES = {
     'av_msckf_batch_push_imu': (C.c_int, [_P, _P, _P, _P, _P, C.c_int]),
     'av_msckf_batch_step': (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P]),
     'av_msckf_batch_submit': (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P]),
+    'av_msckf_batch_device_resident': (C.c_int, [_P]),
+    'av_msckf_batch_submit_dev': (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P]),
     'av_msckf_batch_wait': (C.c_int, [_P, C.c_int]),
     'av_msckf_batch_get_cov': (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     'av_msckf_batch_sizes': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32 * 3)]),

@@ -1007,6 +1007,14 @@ AV_EXPORT int av_frontend_max_features(const av_frontend* fe) { return fe ? fe->
 // pinned slot `slot` (0/1) behind everything already on `stream` and returns; _end waits for exactly those copies and
 // unpacks them into the caller's arrays.  A caller that enqueues the NEXT step between the two keeps the GPU busy while
 // it consumes this frame's features.
+AV_EXPORT int av_frontend_features_dev(av_frontend* fe, const int64_t** ids_dev, const double** uv_dev, const int32_t** n_dev, int* cap)
+{
+    if (!fe || !ids_dev || !uv_dev || !n_dev || !cap) { av_set_error("av_frontend_features_dev: bad arguments"); return AV_E_INVALID; }
+    static_assert(sizeof(long long) == sizeof(int64_t), "feature ids");
+    *ids_dev = reinterpret_cast<const int64_t*>(fe->d.out_ids); *uv_dev = fe->d.out_uv; *n_dev = fe->d.out_n; *cap = fe->d.MAXF;
+    return AV_OK;
+}
+
 AV_EXPORT int av_frontend_read_features_begin(av_frontend* fe, int slot, void* stream)
 {
     if (!fe || slot < 0 || slot > 1) { av_set_error("av_frontend_read_features_begin: bad arguments"); return AV_E_INVALID; }

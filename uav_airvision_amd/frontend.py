@@ -149,6 +149,14 @@ class FrontendEngine(object):
                                                       self._n.ctypes.data_as(C.c_void_p), self.max_features, self._stream()))
         return self._ids, self._uv, self._n
 
+    def features_dev(self):
+        """(ids_ptr, uv_ptr, n_ptr, cap): device addresses of the feature message the last `step` published (int64[S,cap],
+        float64[S,cap,4], int32[S]); rewritten by the next step.  For `BatchedMSCKF.submit_dev`."""
+        ids, uv, n = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        cap = C.c_int(0)
+        N.check(N.lib().av_frontend_features_dev(self._h, C.byref(ids), C.byref(uv), C.byref(n), C.byref(cap)))
+        return ids, uv, n, int(cap.value)
+
     def read_features_begin(self, slot=0):
         """Enqueue the device-to-host copy of the features published by the last step into pinned slot 0/1 (returns
         at once).  Call `step` for the next frame before `read_features_end(slot)` to overlap the two."""

@@ -155,9 +155,11 @@ class BatchedMSCKF(object):
     def __init__(self, config, n_streams, device=0, rows_cap=None, max_features=None):
         """rows_cap: rows of the per-stream block buffer.  None = sized by the library from the capacity of the first
         feature message (the camera-pruning update stacks 5 rows per feature, the lost-feature update at most 1500 + one
-        block); `max_features`, when given, sizes it up front instead.  With the automatic size the FIRST step's
-        `ids.shape[1]` is binding: a later step with a wider array raises AV_E_CAPACITY -- pass max_features (or rows_cap)
-        when the width of the feature arrays can vary.  config.max_cam_state_size <= 24 (reference: 20)."""
+        block); `max_features`, when given, sizes it up front instead.  With the automatic size a later step with a wider
+        `ids.shape[1]` REBUILDS the block buffers and the device-resident observation store for the wider message (drains the
+        batch, synchronises the device, grows by at least x1.5, keeps the outgrown allocations until close) -- pass
+        max_features when the width of the feature arrays can vary.  An explicit rows_cap is never grown.
+        config.max_cam_state_size <= 24 (reference: 20)."""
         if rows_cap is None:
             rows_cap = 0 if max_features is None else max(2048, 5 * int(max_features) + 64)
         self.rows_cap = int(rows_cap)
@@ -232,6 +234,27 @@ class BatchedMSCKF(object):
                                                   nf.ctypes.data_as(C.c_void_p), ids.shape[1], ts.ctypes.data_as(C.c_void_p),
                                                   out.ctypes.data_as(C.c_void_p), N.current_stream()))
         self._inflight.append((ids, uv, nf, ts, out))          # the library reads / writes these until the step retires
+        return out
+
+    def device_resident(self):
+        """True when the filter state and the observation map live on the device (the default; `submit_dev` needs it)."""
+        return N.lib().av_msckf_batch_device_resident(self._h) == 1
+
+    def submit_dev(self, engine, timestamps, msg_stream=None):
+        """Queue one step on the feature message `engine` (a FrontendEngine with the same streams) has just published, read
+        where it lies on the device (av_msckf_batch_submit_dev): no host round trip between the front-end and the filter.
+        msg_stream: the stream handle the engine's step ran on (default: torch's current stream, i.e. call this right after
+        `engine.step` on the same stream).  The filter's kernels run on the current stream / the stream groups' own streams.
+        Returns the float64[S,12] output array, filled once a `wait` has let the step retire."""
+        ids, uv, n, cap = engine.features_dev()
+        ts = np.ascontiguousarray(timestamps, dtype=np.float64)
+        assert ts.shape == (self.S,) and engine.n_streams == self.S
+        out = np.zeros((self.S, 12))
+        with torch.cuda.device(self.device):
+            ms = N.current_stream() if msg_stream is None else msg_stream
+            N.check(N.lib().av_msckf_batch_submit_dev(self._h, ids, uv, n, cap, ts.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                                      ms, N.current_stream()))
+        self._inflight.append((ts, out))
         return out
 
     def wait(self, max_pending=0):

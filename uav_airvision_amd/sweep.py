@@ -65,6 +65,7 @@ class BatchedRunner(object):
         self.eng = FrontendEngine(config, n_streams=self.S, device=self.device)
         self.flt = BatchedMSCKF(config, self.S, device=self.device, rows_cap=rows_cap, max_features=self.eng.max_features)
         self.frames_done = np.zeros(self.S, np.int64)
+        self._fstream = None
 
     def close(self):
         self.eng.close(); self.flt.close()
@@ -94,6 +95,7 @@ class BatchedRunner(object):
         traj = [[] for _ in range(S)]
         last_t = np.zeros(S)
         inflight = []                                     # outputs of submitted steps that have not been recorded yet
+        dev = flt.device_resident()
 
         def record(out):
             for s in range(S):
@@ -136,14 +138,30 @@ class BatchedRunner(object):
                 eng.push_imu_batch(np.array(idx, np.int32), np.array(tt), np.array(gy).reshape(-1, 3))
                 flt.push_imu(idx, tt, gy, ac)
             eng.step_host(img0, img1, ts_e)
-            eng.read_features_begin(step & 1)
-            ids, uv, n = eng.read_features_end(step & 1)
-            n[ts_f < 0] = 0
             if on_step is not None:
+                ids, uv, n = eng.read_features_raw()
+                n[ts_f < 0] = 0
                 out = flt.step(ids, uv, n, ts_f)
                 record(out)
                 on_step(step, ts_f, ids, uv, n, out)
+            elif dev:
+                # the filter reads the published message where it lies on the device; nothing of this step is waited for here:
+                # the next frames are decoded, uploaded and tracked while the filter's groups work through their queues
+                # (a stream without a frame carries timestamp -1: its message is ignored)
+                import torch
+                from . import _native as N
+                if self._fstream is None:
+                    self._fstream = torch.cuda.Stream(device=self.device)
+                ms = N.current_stream()                   # the stream the front-end's step was enqueued on
+                with torch.cuda.stream(self._fstream):    # the filter's kernels (one group: here) overlap the next frame's front-end
+                    inflight.append(flt.submit_dev(eng, ts_f, msg_stream=ms))
+                flt.wait(2)
+                while len(inflight) > 2:
+                    record(inflight.pop(0))
             else:
+                eng.read_features_begin(step & 1)
+                ids, uv, n = eng.read_features_end(step & 1)
+                n[ts_f < 0] = 0
                 inflight.append(flt.submit(ids, uv, n, ts_f))
                 flt.wait(1)                               # at most one step behind: the next frames are decoded meanwhile
                 while len(inflight) > 1:
