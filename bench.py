@@ -704,6 +704,7 @@ def main():
             'kernel_ms_per_step': {k: v[0] / K for k, v in timing.items()},
             'pmc_constants': dict(LK_PMC, fetch_size_factor=FETCH_SIZE_FACTOR, fetch_calibration='profiles/r03/fetch_calib.json'),
             'data_gen_s': gen_s,
+            'filter_state': ('device-resident (state, observation map, selections and injection on the device; the feature message is read from the front-end\'s device buffers)' if (flt is not None and flt.device_resident()) else ('host bookkeeping (AV_MSCKF_STORE=host)' if flt is not None else None)),
             'msckf_in_step': with_msckf, 'msckf_wall_ms_per_step': 1e3 * msckf_s[0] / K, 'msckf_push_imu_ms_per_step': 1e3 * push_s[0] / K,
             'frontend_only_frames_per_s': (world * S * K / fe_elapsed) if fe_elapsed else None,
         }

@@ -2326,6 +2326,7 @@ struct StackArgs {
     int* row_off_w; int* again_list; int* again_count;   //  gated without storage (row_off = -1): the stacked ones get compact offsets here and are listed to run again
     int* clist; int* clist_count;            // out: streams whose stacked rows exceed one back-end pass (compression kernels stride over this list)
     double* work;                            // [S][8] accumulators of av_msckf_batch_work: gate flops, update flops, reference-QR flops, gated, updates, rows
+    int no_info;                             // 1: this phase launches no information-form kernel (every stream takes the Cholesky back end)
 };
 __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
 {
@@ -2391,7 +2392,7 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
     const bool dead = b.mode == 2;                      // stopped by the host (msckf_batch.inc: b_fail_stream): no update, stacked = -1
     const int m = (overflow || dead) ? 0 : stacked;
     // (the information form holds for any m >= 1; a stream the host marked for it never needs a Cholesky round)
-    const int mode = (m > 0 && b.mode == 1 && nc <= INFO_NC && m <= INFO_MAXROWS) ? 1 : 0;
+    const int mode = (m > 0 && b.mode == 1 && !a.no_info && nc <= INFO_NC && m <= INFO_MAXROWS) ? 1 : 0;
     __syncthreads();
     if (lane == 0) {
         int c = 0;
