@@ -355,8 +355,12 @@ class CompletePath(object):
         two steps behind (vio.py:46-51 with the feature queue on the device)."""
         from uav_airvision_amd import _native as N
         torch = self.torch
+        serial = os.environ.get('AV_BENCH_SERIAL')           # diagnostic: front-end and filter strictly alternate (exclusive GPU times add up)
         for k in range(k_begin, k_end):
             self.run_fe(k)
+            if serial:
+                torch.cuda.synchronize()
+                self.fe_excl_s = getattr(self, 'fe_excl_s', 0.0)
             t1 = time.perf_counter()
             i, t, gy, ac = self.imu_flt[k]
             self.flt.push_imu(i, t, gy, ac)
@@ -364,6 +368,8 @@ class CompletePath(object):
             ms = N.current_stream()
             with torch.cuda.stream(self.filt_stream):
                 self.poses.append((k, self.flt.submit_dev(self.eng, np.asarray(self.frame_ts[k], dtype=np.float64), msg_stream=ms)))
+            if serial:
+                self.flt.wait(0)
             self.msckf_s[0] += time.perf_counter() - t1
             if self.step_times is not None:
                 self.step_times.append((k, time.perf_counter()))
@@ -727,7 +733,7 @@ def main():
                        'the reference-size thin QR (2mn^2 - 2/3 n^3, msckf.py:554) listed apart because the column-compressed update never runs it; '
                        'time: HIP events on every stream group\'s stream around the launches of each phase (triangulation .. covariance update), '
                        'summed over the %d groups, inside the timed region of the complete path (so it includes waiting for CUs the front-end holds)'
-                       % int(os.environ.get('AV_MSCKF_GROUPS', '4' if S >= 256 else ('2' if S >= 64 else '1'))),
+                       % int(os.environ.get('AV_MSCKF_GROUPS', ('2' if S >= 1024 else '1') if flt.device_resident() else ('4' if S >= 256 else ('2' if S >= 64 else '1')))),
             }
         if world == 1 and not args.no_cpu_baseline:
             n_traj = (T0 + K) if with_msckf else 0

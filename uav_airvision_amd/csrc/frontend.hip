@@ -1003,10 +1003,7 @@ AV_EXPORT int av_frontend_step_host(av_frontend* fe, const uint8_t* img0_host, c
 
 AV_EXPORT int av_frontend_max_features(const av_frontend* fe) { return fe ? fe->d.MAXF : AV_E_INVALID; }
 
-// Read-back in two halves.  _begin enqueues the device-to-host copies of the features published by the last step into
-// pinned slot `slot` (0/1) behind everything already on `stream` and returns; _end waits for exactly those copies and
-// unpacks them into the caller's arrays.  A caller that enqueues the NEXT step between the two keeps the GPU busy while
-// it consumes this frame's features.
+// The feature_msg of the last step where it lies on the device (consumed by av_msckf_batch_submit_dev)
 AV_EXPORT int av_frontend_features_dev(av_frontend* fe, const int64_t** ids_dev, const double** uv_dev, const int32_t** n_dev, int* cap)
 {
     if (!fe || !ids_dev || !uv_dev || !n_dev || !cap) { av_set_error("av_frontend_features_dev: bad arguments"); return AV_E_INVALID; }
@@ -1015,6 +1012,10 @@ AV_EXPORT int av_frontend_features_dev(av_frontend* fe, const int64_t** ids_dev,
     return AV_OK;
 }
 
+// Read-back in two halves.  _begin enqueues the device-to-host copies of the features published by the last step into
+// pinned slot `slot` (0/1) behind everything already on `stream` and returns; _end waits for exactly those copies and
+// unpacks them into the caller's arrays.  A caller that enqueues the NEXT step between the two keeps the GPU busy while
+// it consumes this frame's features.
 AV_EXPORT int av_frontend_read_features_begin(av_frontend* fe, int slot, void* stream)
 {
     if (!fe || slot < 0 || slot > 1) { av_set_error("av_frontend_read_features_begin: bad arguments"); return AV_E_INVALID; }

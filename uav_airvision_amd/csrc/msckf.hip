@@ -1069,7 +1069,9 @@ constexpr int UT = 1024;
 // (msckf.py:554); any thin QR leaves delta_x and P+ unchanged, so the choice is free.  A Householder QR costs nc
 // dependent reflector steps, the back end scales with k = rows kept: compressing 130 rows to 114 costs more than it
 // saves, compressing 1480 rows to 12 is the whole point.  k never exceeds 144 (S and T^T live in [ld][ld] buffers).
-__host__ __device__ inline bool upd_compress(int m, int nc) { return m > nc && (2 * m > 3 * nc || m > 144); }
+// (136, not 144: the packed triangle of a 136-row Cholesky is 74.6 KB, so TWO upd_chol workgroups share a CU's 160 KB of LDS;
+//  the device-resident path sends streams with more than 136 stacked rows through the compression, msckf_dev_host.inc DEV_KCH.)
+__host__ __device__ inline bool upd_compress(int m, int nc) { return m > nc && (2 * m > 3 * nc || m > 136); }
 __host__ __device__ inline int upd_k(int m, int nc) { return upd_compress(m, nc) ? nc : m; }
 
 __device__ __forceinline__ double block_sum(double v, double* red)
