@@ -48,15 +48,24 @@ def _load_pmc():
         path = os.path.join(ROOT, 'profiles', d, 'pmc_frontend_s64_summary.json')
         if os.path.exists(path):
             e = json.load(open(path))['lk_track_g16_kernel<15>']
-            return dict(path=os.path.relpath(path, ROOT), streams=64, fetch_kb=float(e['FETCH_SIZE']), write_kb=float(e['WRITE_SIZE']),
-                        valu=float(e['SQ_INSTS_VALU']), waves=float(e['SQ_WAVES']))
+            out = dict(path=os.path.relpath(path, ROOT), streams=64, fetch_kb=float(e['FETCH_SIZE']), write_kb=float(e['WRITE_SIZE']),
+                       valu=float(e['SQ_INSTS_VALU']), waves=float(e['SQ_WAVES']), fetch_streams=64)
+            # round 4: FETCH_SIZE measured at the largest batch rocprofv3 --pmc collects on this image (512 streams; it segfaults at
+            # 1,024+), where the pyramids no longer fit the Infinity Cache: per-stream traffic +2.8 % over the 64-stream figure
+            sc = os.path.join(ROOT, 'profiles', 'r04', 'pmc_fetch_scaling.json')
+            if os.path.exists(sc):
+                f = json.load(open(sc))['streams']
+                big = max(f, key=int)
+                out.update(fetch_kb=float(f[big]['lk_track_g16_kernel<15>']['FETCH_SIZE_KB_mean']), fetch_streams=int(big),
+                           fetch_path=os.path.relpath(sc, ROOT))
+            return out
     raise RuntimeError('bench.py: no committed PMC summary under profiles/')
 
 
 FETCH_SIZE_FACTOR = 2.0                             # measured: profiles/r03/fetch_calib.json (raw_over_known = 0.5 for every lane width)
 LK_PMC = _load_pmc()
 LK_PMC_STREAMS = LK_PMC['streams']
-LK_TRAFFIC_BYTES_PER_LAUNCH_S64 = (FETCH_SIZE_FACTOR * LK_PMC['fetch_kb'] + LK_PMC['write_kb']) * 1024
+LK_TRAFFIC_BYTES_PER_LAUNCH_S64 = (FETCH_SIZE_FACTOR * LK_PMC['fetch_kb'] * LK_PMC_STREAMS / LK_PMC['fetch_streams'] + LK_PMC['write_kb']) * 1024      # per 64 streams
 LK_VALU_INSTS_PER_LAUNCH_S64 = LK_PMC['valu']
 FP64_PEAK_TFLOPS = 78.6                             # MI355X_MICROARCH.md: fp64 vector = fp64 matrix peak
 VALU_CYCLES_PER_WAVE_INST = 2.0                     # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
@@ -692,8 +701,10 @@ def main():
                 'bound': 'hbm', 'kernel': 'lk_track_g16_kernel<15>',
                 'achieved': lk_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': lk_gbs / HBM_PEAK_GBS,
                 'traffic': LK_TRAFFIC_BYTES_PER_LAUNCH_S64 * S / LK_PMC_STREAMS,
-                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), %s, FETCH x%.1f (MI355X_MICROARCH.md; confirmed for 4-byte lane '
-                                  'loads by profiles/r03/fetch_calib.json); scaled from 64 streams per launch to %d' % (LK_PMC['path'], FETCH_SIZE_FACTOR, S),
+                'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes): FETCH_SIZE at %d streams per launch (%s: the largest batch '
+                                  'rocprofv3 --pmc collects on this image; per-stream traffic +2.8 %% from 64 to 512 streams), WRITE_SIZE at 64 (%s), FETCH x%.1f '
+                                  '(MI355X_MICROARCH.md; confirmed for 4-byte lane loads by profiles/r03/fetch_calib.json); scaled linearly to %d streams'
+                                  % (LK_PMC['fetch_streams'], LK_PMC.get('fetch_path', LK_PMC['path']), LK_PMC['path'], FETCH_SIZE_FACTOR, S),
                 # the kernel is VALU-issue bound: instructions issued / what the chip's 1,024 SIMDs could issue in the launch's duration
                 'valu_issue_frac': ((LK_VALU_INSTS_PER_LAUNCH_S64 * S / LK_PMC_STREAMS) * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * CLOCK_HZ) / (lk_avg_ms * 1e-3)) if lk_avg_ms > 0 else None,
                 'valu_issue_frac_frontend_only': ((LK_VALU_INSTS_PER_LAUNCH_S64 * S / LK_PMC_STREAMS) * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * CLOCK_HZ) /
@@ -755,6 +766,9 @@ def main():
                     'what': 'stream 0 of the GPU batch (frames 0..%d, pre-roll included) against the CPU port of the reference path on the same '
                             'images and IMU samples; truth = the synthetic trajectory; ATE = RMSE after SE(3) alignment '
                             '(uav_airvision_amd/evaluate.py)' % (T0 + K - 1)}
+        r_ = out['roofline']
+        assert 0.0 < r_['frac'] <= 1.0, 'roofline.frac out of range: %r' % r_['frac']
+        assert r_['traffic'] >= r_['algorithmic_bytes_per_launch'], 'measured HBM traffic below the algorithmic bytes: %r < %r' % (r_['traffic'], r_['algorithmic_bytes_per_launch'])
         print(json.dumps(out))
     eng.close()
     if flt is not None:

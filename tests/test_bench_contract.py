@@ -46,8 +46,15 @@ def test_pmc_constants_come_from_the_committed_summary():
     spec.loader.exec_module(bench)
     path = os.path.join(ROOT, bench.LK_PMC['path'])
     e = json.load(open(path))['lk_track_g16_kernel<15>']
-    assert bench.LK_PMC['fetch_kb'] == e['FETCH_SIZE'] and bench.LK_PMC['write_kb'] == e['WRITE_SIZE'] and bench.LK_PMC['valu'] == e['SQ_INSTS_VALU']
-    assert bench.LK_TRAFFIC_BYTES_PER_LAUNCH_S64 == (bench.FETCH_SIZE_FACTOR * e['FETCH_SIZE'] + e['WRITE_SIZE']) * 1024
+    assert bench.LK_PMC['write_kb'] == e['WRITE_SIZE'] and bench.LK_PMC['valu'] == e['SQ_INSTS_VALU']
+    # round 4: FETCH_SIZE comes from the largest batch rocprofv3 --pmc could collect (profiles/r04/pmc_fetch_scaling.json), scaled to 64 streams
+    sc = json.load(open(os.path.join(ROOT, 'profiles', 'r04', 'pmc_fetch_scaling.json')))
+    big = max(sc['streams'], key=int)
+    f_big = sc['streams'][big]['lk_track_g16_kernel<15>']['FETCH_SIZE_KB_mean']
+    assert bench.LK_PMC['fetch_kb'] == f_big and bench.LK_PMC['fetch_streams'] == int(big) >= 512
+    assert abs(bench.LK_TRAFFIC_BYTES_PER_LAUNCH_S64 - (bench.FETCH_SIZE_FACTOR * f_big * 64 / int(big) + e['WRITE_SIZE']) * 1024) < 1e-6
+    per = sc['lk_fetch_kb_per_stream']                        # the per-stream figure moves by < 5 % between 64 and 512 streams: linear scaling holds
+    assert abs(per[big] / per['64'] - 1.0) < 0.05
     calib = json.load(open(os.path.join(ROOT, 'profiles', 'r03', 'fetch_calib.json')))['kernels']
     for k in ('read16', 'read4', 'read1'):                      # the measured factor: FETCH_SIZE reports half of the bytes, whatever the lane width
         assert abs(1.0 / calib[k]['raw_over_known'] - bench.FETCH_SIZE_FACTOR) < 0.01, k
@@ -57,3 +64,9 @@ def test_pmc_constants_come_from_the_committed_summary():
         d = json.loads(open(f).read().strip().splitlines()[-1])
         if 'pmc_constants' in d and d['pmc_constants']['path'] == bench.LK_PMC['path']:
             assert d['pmc_constants']['fetch_kb'] == e['FETCH_SIZE'] and d['pmc_constants']['valu'] == e['SQ_INSTS_VALU'], f
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r04', 'bench_*.json'))):
+        if 'under_rocprof' in f:
+            continue
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        if 'pmc_constants' in d:
+            assert d['pmc_constants']['fetch_kb'] == f_big and d['pmc_constants']['valu'] == e['SQ_INSTS_VALU'], f
