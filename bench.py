@@ -67,6 +67,7 @@ LK_PMC = _load_pmc()
 LK_PMC_STREAMS = LK_PMC['streams']
 LK_TRAFFIC_BYTES_PER_LAUNCH_S64 = (FETCH_SIZE_FACTOR * LK_PMC['fetch_kb'] * LK_PMC_STREAMS / LK_PMC['fetch_streams'] + LK_PMC['write_kb']) * 1024      # per 64 streams
 LK_VALU_INSTS_PER_LAUNCH_S64 = LK_PMC['valu']
+LK_PMC_POINT_PASSES_PER_STREAM_LAUNCH = 1113.915 / 7.0      # lk_point_passes_per_frame / LK launches per step of the counter runs' workload (grid 4x5x15)
 FP64_PEAK_TFLOPS = 78.6                             # MI355X_MICROARCH.md: fp64 vector = fp64 matrix peak
 VALU_CYCLES_PER_WAVE_INST = 2.0                     # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
@@ -700,14 +701,16 @@ def main():
             'roofline': {
                 'bound': 'hbm', 'kernel': 'lk_track_g16_kernel<15>',
                 'achieved': lk_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': lk_gbs / HBM_PEAK_GBS,
-                'traffic': LK_TRAFFIC_BYTES_PER_LAUNCH_S64 * S / LK_PMC_STREAMS,
+                # the counter passes ran the 300-feature workload (1,113.9 point passes per stream-frame over 7 launches); another grid
+                # changes the points per launch, so the per-launch traffic is scaled by point passes as well as by streams
+                'traffic': LK_TRAFFIC_BYTES_PER_LAUNCH_S64 * S / LK_PMC_STREAMS * ((p_frame / lk_launches_per_step) / LK_PMC_POINT_PASSES_PER_STREAM_LAUNCH),
                 'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes): FETCH_SIZE at %d streams per launch (%s: the largest batch '
                                   'rocprofv3 --pmc collects on this image; per-stream traffic +2.8 %% from 64 to 512 streams), WRITE_SIZE at 64 (%s), FETCH x%.1f '
                                   '(MI355X_MICROARCH.md; confirmed for 4-byte lane loads by profiles/r03/fetch_calib.json); scaled linearly to %d streams'
                                   % (LK_PMC['fetch_streams'], LK_PMC.get('fetch_path', LK_PMC['path']), LK_PMC['path'], FETCH_SIZE_FACTOR, S),
                 # the kernel is VALU-issue bound: instructions issued / what the chip's 1,024 SIMDs could issue in the launch's duration
-                'valu_issue_frac': ((LK_VALU_INSTS_PER_LAUNCH_S64 * S / LK_PMC_STREAMS) * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * CLOCK_HZ) / (lk_avg_ms * 1e-3)) if lk_avg_ms > 0 else None,
-                'valu_issue_frac_frontend_only': ((LK_VALU_INSTS_PER_LAUNCH_S64 * S / LK_PMC_STREAMS) * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * CLOCK_HZ) /
+                'valu_issue_frac': ((LK_VALU_INSTS_PER_LAUNCH_S64 * S / LK_PMC_STREAMS * ((p_frame / lk_launches_per_step) / LK_PMC_POINT_PASSES_PER_STREAM_LAUNCH)) * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * CLOCK_HZ) / (lk_avg_ms * 1e-3)) if lk_avg_ms > 0 else None,
+                'valu_issue_frac_frontend_only': ((LK_VALU_INSTS_PER_LAUNCH_S64 * S / LK_PMC_STREAMS * ((p_frame / lk_launches_per_step) / LK_PMC_POINT_PASSES_PER_STREAM_LAUNCH)) * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * CLOCK_HZ) /
                                                   (timing_fe['lk'][0] / max(timing_fe['lk'][1], 1) * 1e-3)) if timing_fe else None,
                 'note': 'lk_track_g16_kernel is VALU-issue bound (PMC at 64 streams: 21.4 M VALU wave-instructions per launch on the mean over a step\'s launch mix, 38% of wave '
                         'cycles waiting on an instruction, LDS 2% of instructions); its tiles come from L2/Infinity Cache. The HBM fraction is '

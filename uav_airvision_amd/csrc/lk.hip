@@ -527,6 +527,9 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
 // 96 VGPRs: 5 waves per SIMD without spills (the kernel is VALU-issue bound: 4 -> 5 waves bought 1 %, a 6-wave build with
 // 11 spilled values lost 5 %).
 template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_kernel(LKArgs a) { lk_track_g16_body<WIN, 5>(a); }
+// A/B (AV_LK_WAVES=4): the same body held to four waves per SIMD -- 128 of a SIMD's 512 VGPR rows stay free, room for one wave of
+// the filter's fp64 kernels (64-128 VGPRs) beside four LK waves; with five LK waves (480 rows) no filter wave fits until one retires.
+template <int WIN> __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(256) void lk_track_g16_kernel_w4(LKArgs a) { lk_track_g16_body<WIN, 4>(a); }
 
 }  // namespace
 
@@ -551,7 +554,9 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
     const int gx = (launch_pts + 15) / 16;
     a.n_set = n_set; a.gx = xcd_map ? gx : 0;
     dim3 grid = xcd_map ? dim3((unsigned)gx * 8u * (unsigned)((n_set + 7) / 8)) : dim3(gx, n_set);
-    hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
+    static const bool w4 = [] { const char* e = getenv("AV_LK_WAVES"); return e && atoi(e) == 4; }();
+    if (w4) hipLaunchKernelGGL(lk_track_g16_kernel_w4<15>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

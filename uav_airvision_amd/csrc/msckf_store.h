@@ -202,9 +202,11 @@ AVS_FN int avs_add_frame(const AvsTeam& T, const AvsStore& V, const long long* i
     return slot;
 }
 
-// Stable ordering of `n` feature slots by birth (dict order): out[rank] = in[i].  Births are distinct, so the rank of an item
-// is the number of items born before it -- no barriers inside, any memory.  n is a few dozen in a steady frame.
-AVS_FN void avs_sort_by_birth(const AvsTeam& T, const AvsStore& V, const int* in, int n, int* out, int* aux_in = nullptr, int* aux_out = nullptr)
+// Ordering of `n` feature slots by birth (dict order): out[rank] = in[i], and the same permutation for up to two companion arrays.
+// Births are distinct, so the rank of an item is the number of items born before it -- no barriers inside the count, any memory
+// for the keys (V.keys: the kernels point it at LDS when the list fits, which makes the n reads per item broadcasts).
+AVS_FN void avs_sort_by_birth(const AvsTeam& T, const AvsStore& V, const int* in, int n, int* out,
+                              const int* a0_in = nullptr, int* a0_out = nullptr, const int* a1_in = nullptr, int* a1_out = nullptr)
 {
     for (int i = T.tid(); i < n; i += T.nt()) V.keys[i] = (unsigned long long)V.m_birth[in[i]];
     T.sync();
@@ -213,7 +215,8 @@ AVS_FN void avs_sort_by_birth(const AvsTeam& T, const AvsStore& V, const int* in
         int r = 0;
         for (int j = 0; j < n; ++j) r += V.keys[j] < k;
         out[r] = in[i];
-        if (aux_in) aux_out[r] = aux_in[i];
+        if (a0_in) a0_out[r] = a0_in[i];
+        if (a1_in) a1_out[r] = a1_in[i];
     }
     T.sync();
 }
@@ -301,8 +304,7 @@ AVS_FN void avs_select_prune(const AvsTeam& T, const AvsStore& V, int i0, int i1
         nc += tc;
     }
     T.sync();
-    avs_sort_by_birth(T, V, V.tmp_a, nc, cand, V.tmp_b, e1);
-    avs_sort_by_birth(T, V, V.tmp_a, nc, cand, V.tmp_c, e0);
+    avs_sort_by_birth(T, V, V.tmp_a, nc, cand, V.tmp_b, e1, V.tmp_c, e0);
     *n_cand = nc;
 }
 
