@@ -69,6 +69,8 @@ int av_pyramid_build(const uint8_t* img_dev, int64_t img_stride, int n_img, int 
  * Batched over n_set point sets: set i tracks count_dev[i] (<= cap) points from pyramid
  * pyrI_dev + i*pyr_stride into pyrJ_dev + i*pyr_stride.  prev/next are float32 (x,y) pairs at
  * [i*cap + k]; next holds the initial guess on entry and the result on return; status is u8.
+ * win: 3 .. 31 (config.win_size: the reference's 15 x 15 runs the 16-lanes-per-point kernel, any other size the general
+ * one-wavefront-per-point kernel: same arithmetic, same results rule -- bit-identical to the CPU oracle); levels: 1 .. AV_MAX_LEVELS.
  * ------------------------------------------------------------------------------------------- */
 int av_lk_track(const uint8_t* pyrI_dev, const uint8_t* pyrJ_dev, int64_t pyr_stride, int n_set,
                 int w, int h, int levels,
@@ -114,7 +116,7 @@ typedef struct av_frontend_config {
     int32_t grid_min_feature_num;            /* config.py:26                                        */
     int32_t grid_max_feature_num;            /* config.py:27                                        */
     int32_t fast_threshold;                  /* config.py:28                                        */
-    int32_t lk_win;                          /* config.patch_size (config.py:35)                    */
+    int32_t lk_win;                          /* config.patch_size (config.py:35); 3 .. 31           */
     int32_t lk_levels;                       /* config.pyramid_levels + 1 (config.py:34)            */
     int32_t lk_max_iter;                     /* config.max_iteration (config.py:31)                 */
     int32_t max_corners;                     /* capacity for FAST keypoints of one image            */

@@ -95,6 +95,25 @@ def test_engine_matches_oracle_300_features_fast_motion():
     _compare(ref, got[0], 'n300')
 
 
+@pytest.mark.parametrize('win,levels', [(21, 2), (9, 4)])
+def test_engine_matches_oracle_with_another_lk_window_and_pyramid_depth(win, levels):
+    """`config.win_size` / `config.pyramid_levels` are configuration (config.py:31-44), not constants of the path: a 21 x 21 window
+    over 3 pyramid levels and a 9 x 9 window over 5 go through the whole engine (temporal + stereo LK on the general kernel) and
+    must match the CPU oracle frame by frame, ids and coordinates bit for bit, like the 15 x 15 / 4-level default."""
+    from uav_airvision_amd.config import ConfigEuRoC
+    from uav_airvision_amd.synth import SyntheticStream
+    cfg = ConfigEuRoC()
+    cfg.patch_size = win
+    cfg.win_size = (win, win)
+    cfg.pyramid_levels = levels
+    cfg.lk_params = dict(cfg.lk_params, winSize=cfg.win_size, maxLevel=levels)
+    st = SyntheticStream(cfg, seed=9, n_frames=6, motion_scale=1.5)
+    got = _run_engine(cfg, [st])
+    ref = _run_oracle(cfg, st)
+    assert len(ref[-1][0]) > 40
+    _compare(ref, got[0], 'win%d_levels%d' % (win, levels))
+
+
 def test_engine_capacity_overflow_is_reported(cfg):
     from uav_airvision_amd._native import AirvisionError
     from uav_airvision_amd.synth import SyntheticStream

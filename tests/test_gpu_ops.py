@@ -75,6 +75,28 @@ def test_lk_stereo_and_edge_cases_bit_exact(ops, frames0, cfg):
     assert np.array_equal(p_gpu.view(np.uint32), p_cpu.view(np.uint32))
 
 
+@pytest.mark.parametrize('win,max_level', [(9, 3), (21, 3), (31, 2), (16, 1), (5, 4), (15, 1), (15, 4)])
+def test_lk_other_windows_and_levels_bit_exact(ops, frames0, win, max_level):
+    """config.win_size / pyramid levels other than the reference's defaults (config.py:31-44 are configuration, not constants):
+    windows other than 15 take the general one-wavefront-per-point kernel, 15 x 15 with another maxLevel the 16-lane kernel.
+    Same bar as the default: status equal, points bit-identical, incl. points outside the image and windows that leave it."""
+    from oracle import cvops
+    rng = np.random.default_rng(100 + win)
+    xs, ys, _ = cvops.fast_detect(frames0[0].cam0_image, 15)
+    sel = np.linspace(0, len(xs) - 1, 260).astype(int)
+    prev = np.concatenate([np.stack([xs[sel], ys[sel]], 1).astype(np.float32) + np.float32(0.25),
+                           np.stack([rng.uniform(-25, 777, 60), rng.uniform(-25, 505, 60)], 1).astype(np.float32)])
+    init = prev + rng.normal(0, 3, prev.shape).astype(np.float32)
+    init[-10:] += 400.0
+    kw = dict(winSize=(win, win), maxLevel=max_level, criteria=(3, 30, 0.01), flags=4, minEigThreshold=1e-4)
+    for I, J in ((frames0[0].cam0_image, frames0[1].cam0_image), (frames0[2].cam0_image, frames0[2].cam1_image)):
+        p_gpu, s_gpu, _ = ops.calc_optical_flow_pyr_lk(I, J, prev, init, **kw)
+        p_cpu, s_cpu, _ = cvops.calc_optical_flow_pyr_lk(I, J, prev, init, **kw)
+        assert np.array_equal(s_gpu, s_cpu), (win, max_level, int((s_gpu != s_cpu).sum()))
+        assert 50 < s_cpu.sum() < len(prev)
+        assert np.array_equal(p_gpu.view(np.uint32), p_cpu.view(np.uint32)), (win, max_level, np.abs(p_gpu - p_cpu).max())
+
+
 def test_lk_flat_image_fails_min_eig(ops, cfg):
     I = np.full((480, 752), 90, np.uint8)
     prev = np.array([[100.5, 100.25], [300, 200]], np.float32)

@@ -820,7 +820,7 @@ AV_EXPORT int av_frontend_create(const av_frontend_config* cfg, int n_streams, i
     double e = cfg->lk_eps < 0 ? 0. : (cfg->lk_eps > 10. ? 10. : cfg->lk_eps);
     fe->lk.eps2 = e * e;
     fe->lk.min_eig = cfg->lk_min_eig;
-    if (fe->lk.win != 15) { av_set_error("av_frontend_create: only lk_win = 15 is built"); delete fe; return AV_E_INVALID; }
+    if (fe->lk.win < 3 || fe->lk.win > 31) { av_set_error("av_frontend_create: lk_win %d outside 3 .. 31", fe->lk.win); delete fe; return AV_E_INVALID; }      // 15: the 16-lane kernel; others: the general one
 
     FeDev& d = fe->d;
     memset(&d, 0, sizeof(d));

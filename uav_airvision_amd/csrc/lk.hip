@@ -531,6 +531,161 @@ template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_kernel
 // the filter's fp64 kernels (64-128 VGPRs) beside four LK waves; with five LK waves (480 rows) no filter wave fits until one retires.
 template <int WIN> __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(256) void lk_track_g16_kernel_w4(LKArgs a) { lk_track_g16_body<WIN, 4>(a); }
 
+
+// =================================================================================================
+// Any other window (config.win_size, src/config.py:35-38; 3 <= win <= 31): one WAVEFRONT per point, the win x win window
+// pixels dealt over the 64 lanes (at most 16 per lane, the I / Ix / Iy values of a lane's pixels in registers), the same
+// arithmetic in the same order as the 16-lane kernel and the oracle: W_BITS = 14 bilinear weights, Scharr derivatives of the
+// first image taken at integer pixels (BORDER_REFLECT_101 neighbours inside the image, zero outside), exact integer window
+// sums (int64 per lane, butterfly over the wavefront) rounded once, float Newton steps.  Pixels are read straight from the
+// padded pyramid level (or the caller's image for level 0) through the cache -- this is the general path, not the fast one.
+// =================================================================================================
+constexpr int LKG_MAX_WIN = 31, LKG_PER_LANE = (LKG_MAX_WIN * LKG_MAX_WIN + 63) / 64;
+
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+struct LKLevel { const uint8_t* base; int pitch, w, h; };      // base = address of pixel (0, 0)
+__device__ __forceinline__ int lkg_pix(const LKLevel& L, int x, int y) { return L.base[(size_t)av_reflect101(y, L.h) * L.pitch + av_reflect101(x, L.w)]; }
+
+__global__ __launch_bounds__(256) void lk_track_generic_kernel(LKArgs a, int WIN)
+{
+    constexpr int W_BITS = 14;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.y, slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = min(a.count[s], a.cap);
+    if (slot >= n) return;                                   // wave-uniform
+    const int pidx = a.index ? a.index[(size_t)s * a.cap + slot] : slot;
+    const size_t pi = (size_t)s * a.cap + pidx;
+    const float prevx0 = a.prev[2 * pi], prevy0 = a.prev[2 * pi + 1];
+    float curx = a.next[2 * pi], cury = a.next[2 * pi + 1];
+    const float halfWin = (WIN - 1) * 0.5f;
+    const int win2 = WIN * WIN;
+    const double FLT_SCALE_D = 1.0 / (1 << 20);
+    bool ok = true;
+    for (int level = a.g.levels - 1; level >= 0; --level) {
+        const int w = a.g.w[level], h = a.g.h[level];
+        LKLevel LI, LJ;
+        {
+            const bool extI = level == 0 && a.imgI != nullptr, extJ = level == 0 && a.imgJ != nullptr;
+            const int pitch = a.g.pitch[level];
+            LI.base = extI ? a.imgI + (size_t)s * (size_t)a.imgI_stride : a.pyrI + s * a.stream_stride + a.g.off[level] + (size_t)AV_PYR_BORDER * pitch + AV_PYR_BORDER;
+            LI.pitch = extI ? w : pitch; LI.w = w; LI.h = h;
+            LJ.base = extJ ? a.imgJ + (size_t)s * (size_t)a.imgJ_stride : a.pyrJ + s * a.stream_stride + a.g.off[level] + (size_t)AV_PYR_BORDER * pitch + AV_PYR_BORDER;
+            LJ.pitch = extJ ? w : pitch; LJ.w = w; LJ.h = h;
+        }
+        const float scale = (float)(1. / (1 << level));
+        float pvx = prevx0 * scale, pvy = prevy0 * scale;
+        if (level == a.g.levels - 1) { curx = curx * scale; cury = cury * scale; }
+        else                         { curx = curx * 2.f;   cury = cury * 2.f; }
+        pvx -= halfWin; pvy -= halfWin;
+        const int ipx = (int)floorf(pvx), ipy = (int)floorf(pvy);
+        if (ipx < -WIN || ipx >= w || ipy < -WIN || ipy >= h) {
+            if (level == 0) ok = false;
+            continue;
+        }
+        float fa = pvx - ipx, fb = pvy - ipy;
+        int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+        int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+        int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        // ---- I patch and derivative patches of this lane's window pixels
+        short iv[LKG_PER_LANE], ixv[LKG_PER_LANE], iyv[LKG_PER_LANE];
+        long long sA11 = 0, sA12 = 0, sA22 = 0;
+#pragma unroll
+        for (int t = 0; t < LKG_PER_LANE; ++t) {
+            const int idx = lane + 64 * t;
+            iv[t] = 0; ixv[t] = 0; iyv[t] = 0;
+            if (idx < win2) {
+                const int y = idx / WIN, x = idx - y * WIN, X = ipx + x, Y = ipy + y;
+                // 4 x 4 neighbourhood (X-1 .. X+2, Y-1 .. Y+2), reflected: the four bilinear taps and their Scharr stencils
+                int P[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) P[r][c] = lkg_pix(LI, X - 1 + c, Y - 1 + r);
+                const int ival = AV_DESCALE(P[1][1] * iw00 + P[1][2] * iw01 + P[2][1] * iw10 + P[2][2] * iw11, W_BITS - 5);
+                // derivative at the integer pixel (X + cx, Y + cy), cx, cy in {0, 1}: zero outside the image (calc() pads the derivative
+                // image with BORDER_CONSTANT), else Scharr over reflected neighbours.  The stencil of (X+cx, Y+cy) needs pixels
+                // X+cx-1 .. X+cx+1: for cx = 1 that is X .. X+2, all inside P; reflection of a neighbour of an INSIDE pixel equals the
+                // reflected read already taken (reflect101 is applied per coordinate).
+                int dxv[2][2], dyv[2][2];
+#pragma unroll
+                for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                    for (int cx = 0; cx < 2; ++cx) {
+                        const bool in = (unsigned)(X + cx) < (unsigned)w && (unsigned)(Y + cy) < (unsigned)h;
+                        // t0(c) = (above + below) * 3 + centre * 10, t1(c) = below - above, at columns cx-1 .. cx+1 (P columns cx .. cx+2)
+                        int t0[3], t1[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { t0[k] = (P[cy][cx + k] + P[cy + 2][cx + k]) * 3 + P[cy + 1][cx + k] * 10; t1[k] = P[cy + 2][cx + k] - P[cy][cx + k]; }
+                        dxv[cy][cx] = in ? (int)(short)(t0[2] - t0[0]) : 0;
+                        dyv[cy][cx] = in ? (int)(short)((t1[2] + t1[0]) * 3 + t1[1] * 10) : 0;
+                    }
+                const int ix = AV_DESCALE(dxv[0][0] * iw00 + dxv[0][1] * iw01 + dxv[1][0] * iw10 + dxv[1][1] * iw11, W_BITS);
+                const int iy = AV_DESCALE(dyv[0][0] * iw00 + dyv[0][1] * iw01 + dyv[1][0] * iw10 + dyv[1][1] * iw11, W_BITS);
+                iv[t] = (short)ival; ixv[t] = (short)ix; iyv[t] = (short)iy;
+                sA11 += (long long)ixv[t] * ixv[t]; sA12 += (long long)ixv[t] * iyv[t]; sA22 += (long long)iyv[t] * iyv[t];
+            }
+        }
+        const float A11 = (float)((double)wave_sum_i64(sA11) * FLT_SCALE_D);
+        const float A12 = (float)((double)wave_sum_i64(sA12) * FLT_SCALE_D);
+        const float A22 = (float)((double)wave_sum_i64(sA22) * FLT_SCALE_D);
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+        if ((double)minEig < a.min_eig || D < 1.1920928955078125e-7f) {
+            if (level == 0) ok = false;
+            continue;
+        }
+        D = 1.f / D;
+        float wx = curx - halfWin, wy = cury - halfWin;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < a.max_iter; ++j) {
+            const int inx = (int)floorf(wx), iny = (int)floorf(wy);
+            if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) {
+                if (level == 0) ok = false;
+                break;
+            }
+            fa = wx - inx; fb = wy - iny;
+            iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+            iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+            iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            long long sb1 = 0, sb2 = 0;
+#pragma unroll
+            for (int t = 0; t < LKG_PER_LANE; ++t) {
+                const int idx = lane + 64 * t;
+                if (idx < win2) {
+                    const int y = idx / WIN, x = idx - y * WIN, X = inx + x, Y = iny + y;
+                    const int diff = AV_DESCALE(lkg_pix(LJ, X, Y) * iw00 + lkg_pix(LJ, X + 1, Y) * iw01 + lkg_pix(LJ, X, Y + 1) * iw10 + lkg_pix(LJ, X + 1, Y + 1) * iw11, W_BITS - 5) - iv[t];
+                    sb1 += (long long)diff * ixv[t]; sb2 += (long long)diff * iyv[t];
+                }
+            }
+            const float fb1 = (float)((double)wave_sum_i64(sb1) * FLT_SCALE_D);
+            const float fb2 = (float)((double)wave_sum_i64(sb2) * FLT_SCALE_D);
+            const float dx = (A12 * fb2 - A22 * fb1) * D;
+            const float dy = (A12 * fb1 - A11 * fb2) * D;
+            wx += dx; wy += dy;
+            curx = wx + halfWin; cury = wy + halfWin;
+            if ((double)dx * dx + (double)dy * dy <= a.eps2) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                curx -= dx * 0.5f; cury -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+    }
+    if (lane == 0) {
+        a.next[2 * pi] = curx;
+        a.next[2 * pi + 1] = cury;
+        a.status[pi] = ok ? 1 : 0;
+    }
+}
+
 }  // namespace
 
 int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride, int n_set, const PyrGeom& g,
@@ -539,17 +694,19 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
                  const uint8_t* imgI, int64_t imgI_stride, const uint8_t* imgJ, int64_t imgJ_stride)
 {
     if (n_set <= 0 || launch_pts <= 0) return AV_OK;
-    if (p.win != 15) {
-        av_set_error("av_lk_track: only winSize 15x15 is built (the reference's config.py:35); got %d", p.win);
-        return AV_E_INVALID;
-    }
-    if (p.win + 1 > AV_PYR_BORDER) { av_set_error("av_lk_track: window exceeds pyramid frame"); return AV_E_INVALID; }
+    if (p.win < 3 || p.win > LKG_MAX_WIN) { av_set_error("av_lk_track: winSize %d outside 3 .. %d", p.win, LKG_MAX_WIN); return AV_E_INVALID; }
     LKArgs a;
     a.pyrI = pyrI; a.pyrJ = pyrJ; a.stream_stride = stream_stride; a.g = g;
     a.prev = prev; a.next = next; a.status = status; a.count = count; a.index = index; a.cap = cap;
     a.max_iter = p.max_iter; a.eps2 = p.eps2; a.min_eig = p.min_eig;
     a.imgI = imgI; a.imgJ = imgJ; a.imgI_stride = imgI_stride; a.imgJ_stride = imgJ_stride;
     if (launch_pts > cap) launch_pts = cap;
+    if (p.win != 15) {           // any other window of config.win_size: the general kernel (one wavefront per point)
+        a.n_set = n_set; a.gx = 0;
+        hipLaunchKernelGGL(lk_track_generic_kernel, dim3((launch_pts + 3) / 4, n_set), dim3(256), 0, st, a, p.win);
+        AV_LAUNCH_CHECK();
+        return AV_OK;
+    }
     static const bool xcd_map = [] { const char* e = getenv("AV_LK_XCD"); return !(e && atoi(e) == 0); }();      // A/B switch
     const int gx = (launch_pts + 15) / 16;
     a.n_set = n_set; a.gx = xcd_map ? gx : 0;
