@@ -337,7 +337,7 @@ struct FeatArgs {
 };
 
 // dynamic LDS of feature_kernel for tracks of at most Mx observations (layout at the top of the kernel)
-static inline size_t feature_lds_bytes(int Mx, int team = 256)
+__host__ __device__ static inline size_t feature_lds_bytes(int Mx, int team = 256)
 {
     const size_t red = team == 256 ? 256 : 0;           // tree-reduction scratch of the workgroup teams only
     // Hb [4Mx][6] + alpha [3][6Mx] + Hf [4Mx][3] + r [4Mx] + S [4Mx][4Mx+1] (+ reduction scratch) + camera indices
@@ -1988,12 +1988,18 @@ static inline size_t upd_info_lds(int nc, int n, int m)
     return sizeof(double) * ((size_t)nc * nc + nc + (size_t)nc * (n + 1) + (size_t)nc * (nc + n + 2) + (size_t)INFO_CH * (INFO_NC + 1)) + sizeof(int) * ((size_t)m + 2) + 64;
 }
 
+__device__ __forceinline__ void upd_info_body(const UpdArgs& a, double* Li);
 __global__ __launch_bounds__(256) void upd_info_kernel(const UpdArgs* __restrict__ arr)
 {
     AV_FILTER_PRIO();
-    extern __shared__ double Li[];
+    extern __shared__ double Li_dyn[];
     const UpdArgs a = arr[blockIdx.x];
     if (a.m <= 0 || a.mode != 1) return;
+    upd_info_body(a, Li_dyn);
+}
+// (also called by the fused pruning kernel of the device-resident filter, msckf_dev.inc: dk_prune)
+__device__ __forceinline__ void upd_info_body(const UpdArgs& a, double* Li)
+{
     const int tid = threadIdx.x, n = a.n, nc = a.nc, nb = a.n_blk;
     double* A = Li;                          // [nc][nc]
     double* bv = A + nc * nc;                // [nc]
