@@ -57,6 +57,71 @@ def test_png_decoder_matches_pillow_on_every_filter_type(tmp_path):
     assert np.array_equal(out2[0], imgs[0]) and (out2[1] == 7).all() and np.array_equal(out2[2], imgs[2])
 
 
+def _write_png_with_filters(path, img, filters, level=6, idat=1 << 30):
+    """A greyscale PNG whose row r uses PNG filter type filters[r] (spec 9.2, bpp = 1): the encoder side of the decoder under test."""
+    import struct, zlib
+    h, w = img.shape
+    a = img.astype(np.int32)
+    left = np.concatenate([np.zeros((h, 1), np.int32), a[:, :-1]], 1)
+    up = np.concatenate([np.zeros((1, w), np.int32), a[:-1]], 0)
+    ul = np.concatenate([np.zeros((h, 1), np.int32), up[:, :-1]], 1)
+    pp = left + up - ul
+    pa, pb, pc = np.abs(pp - left), np.abs(pp - up), np.abs(pp - ul)
+    paeth = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, ul))
+    pred = [np.zeros_like(a), left, up, (left + up) >> 1, paeth]
+    rows = b''.join(bytes([f]) + ((a[r] - pred[f][r]) & 0xFF).astype(np.uint8).tobytes() for r, f in enumerate(filters))
+    z = zlib.compress(rows, level)
+
+    def chunk(t, d):
+        return struct.pack('>I', len(d)) + t + d + struct.pack('>I', zlib.crc32(t + d) & 0xFFFFFFFF)
+    open(path, 'wb').write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, 0, 0, 0, 0))
+                           + b''.join(chunk(b'IDAT', z[i:i + idat]) for i in range(0, len(z), idat)) + chunk(b'IEND', b''))
+
+
+@pytest.mark.parametrize('backend', ['libdeflate', 'zlib'])
+def test_png_decoder_row_filter_runs_and_both_inflate_back_ends(tmp_path, backend):
+    """Paeth rows are un-filtered eight at a time (SSE2 lanes), four at a time or singly depending on how many line up, and the
+    deflate stream is inflated by libdeflate or by zlib (AV_PNG_ZLIB=1, read when the library is first used: a child process)."""
+    import subprocess, sys, textwrap
+    rng = np.random.default_rng(11)
+    cases = []
+    for i, (h, w) in enumerate([(480, 752), (37, 16), (41, 15), (64, 100), (9, 752)]):
+        img = np.clip(rng.normal(120, 40, (h, w)) + 50 * np.sin(np.arange(w) / 9.0)[None, :], 0, 255).astype(np.uint8)
+        if i == 0:            # runs of Paeth rows of every length 1..20 separated by one row of another type; the first row Paeth too
+            f = [4]
+            run = 1
+            while len(f) < h:
+                f += [4] * run + [int(rng.integers(0, 4))]
+                run = run % 20 + 1
+            f = f[:h]
+        elif i == 4:
+            f = [4] * h      # all Paeth: row 0 alone, then one group of eight
+        else:
+            f = [int(v) for v in rng.integers(0, 5, h)]
+            f[h // 2:h // 2 + 17] = [4] * 17
+        path = str(tmp_path / ('f%d.png' % i))
+        _write_png_with_filters(path, img, f, level=[1, 6, 9][i % 3], idat=(1 << 30) if i % 2 else 5000)
+        np.save(str(tmp_path / ('f%d.npy' % i)), img)
+        assert np.array_equal(np.asarray(Image.open(path)), img)            # the writer above is a valid encoder
+        cases.append((path, h, w))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        from uav_airvision_amd.euroc import decode_batch
+        for a in sys.argv[1:]:
+            path, h, w = a.split(','); h = int(h); w = int(w)
+            out = np.zeros((1, h, w), np.uint8)
+            decode_batch([path], out)
+            assert np.array_equal(out[0], np.load(path[:-4] + '.npy')), path
+        print('ok')
+    """)
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env.pop('AV_PNG_ZLIB', None)
+    if backend == 'zlib':
+        env['AV_PNG_ZLIB'] = '1'
+    r = subprocess.run([sys.executable, '-c', code] + ['%s,%d,%d' % c for c in cases], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
+
+
 def test_png_decoder_other_flavours_and_errors(tmp_path):
     rng = np.random.default_rng(4)
     g = rng.integers(0, 256, (480, 752), dtype=np.uint8)

@@ -55,7 +55,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError('hipcc failed for: ' + ', '.join(failed))
     if force or procs or _stale(OUT, objs):
-        cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-fopenmp', '-Wl,-rpath,/opt/rocm/lib/llvm/lib', '-o', OUT] + objs + ['-lz']
+        cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-fopenmp', '-Wl,-rpath,/opt/rocm/lib/llvm/lib', '-o', OUT] + objs + ['-lz', '-ldl']
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)

@@ -386,11 +386,13 @@ __device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, d
     double* Hout = a.Hout + sidx * a.h_stride;
     double* rout = a.rout + sidx * a.r_stride;
     const double* grav = a.stream_gravity ? a.stream_gravity + 3 * sidx : a.gravity;
-    const int o0 = a.obs_off[f], M = a.obs_off[f + 1] - o0;
+    // 16-lane teams only ever see two-observation features (the pruning candidates: one observation from each of the two cameras
+    // that go; launch_feature_kernel picks them for Mmax <= 2): M is a compile-time constant there and every loop below unrolls
+    const int o0 = a.obs_off[f], M = TEAM == 16 ? 2 : a.obs_off[f + 1] - o0;
     const int R4 = 4 * M, C6 = 6 * M, K = R4 - 3;
-    const int Mx = a.Mmax;
+    const int Mx = TEAM == 16 ? 2 : a.Mmax;
     const int tri = a.tri_idx ? a.tri_idx[f] : -1;
-    if (tri == -2 || (tri >= 0 && !a.tri_valid[tri]) || (a.valid && !a.valid[f])) {   // -2: failed check_motion on the host                  // whole team (uniform in f): triangulation failed, nothing to gate
+    if (tri == -2 || (tri >= 0 && !a.tri_valid[tri]) || (a.valid && !a.valid[f]) || (TEAM == 16 && a.obs_off[f + 1] - o0 != 2)) {   // -2: failed check_motion on the host                  // whole team (uniform in f): triangulation failed, nothing to gate
         if (tid == 0) { a.gamma[f] = 0.0; a.pass[f] = 0; }
         return;
     }
@@ -787,29 +789,31 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
     const int N = IMU_DIM;
     for (int i = tid; i < N * N; i += 256) F[i] = 0.0;
     for (int i = tid; i < N * 12; i += 256) G[i] = 0.0;
-    if (tid == 0) { quat_to_rot(a.q_old, Rwi); quat_to_rot(a.q_null, Rnull); quat_to_rot(a.q_new, Rnew); }
+    // the scalar preparation is spread over the first lanes of three wavefronts (it used to be lane 0's alone: with the back end batched
+    // this serial stretch, not the 21 x 21 products, was most of a sample's time)
+    if ((tid & 63) == 0 && tid < 192) quat_to_rot(tid == 0 ? a.q_old : (tid == 64 ? a.q_null : a.q_new), tid == 0 ? Rwi : (tid == 64 ? Rnull : Rnew));
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 9) {
+        const int r = tid / 3, c = tid - 3 * r;
         const double* w = a.gyro; const double* ac = a.acc;
-        double skw[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
-        double ska[9] = {0, -ac[2], ac[1], ac[2], 0, -ac[0], -ac[1], ac[0], 0};
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) {
-                F[r * N + c] = -skw[r * 3 + c];
-                F[r * N + 3 + c] = r == c ? -1.0 : 0.0;
-                double s = 0;
-                for (int k = 0; k < 3; ++k) s += Rwi[k * 3 + r] * ska[k * 3 + c];          // R^T skew(acc)
-                F[(6 + r) * N + c] = -s;
-                F[(6 + r) * N + 9 + c] = -Rwi[c * 3 + r];
-                F[(12 + r) * N + 6 + c] = r == c ? 1.0 : 0.0;
-                G[r * 12 + c] = r == c ? -1.0 : 0.0;
-                G[(3 + r) * 12 + 3 + c] = r == c ? 1.0 : 0.0;
-                G[(6 + r) * 12 + 6 + c] = -Rwi[c * 3 + r];
-                G[(9 + r) * 12 + 9 + c] = r == c ? 1.0 : 0.0;
-            }
+        const double skw[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+        const double ska[9] = {0, -ac[2], ac[1], ac[2], 0, -ac[0], -ac[1], ac[0], 0};
+        F[r * N + c] = -skw[r * 3 + c];
+        F[r * N + 3 + c] = r == c ? -1.0 : 0.0;
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += Rwi[k * 3 + r] * ska[k * 3 + c];          // R^T skew(acc)
+        F[(6 + r) * N + c] = -s;
+        F[(6 + r) * N + 9 + c] = -Rwi[c * 3 + r];
+        F[(12 + r) * N + 6 + c] = r == c ? 1.0 : 0.0;
+        G[r * 12 + c] = r == c ? -1.0 : 0.0;
+        G[(3 + r) * 12 + 3 + c] = r == c ? 1.0 : 0.0;
+        G[(6 + r) * 12 + 6 + c] = -Rwi[c * 3 + r];
+        G[(9 + r) * 12 + 9 + c] = r == c ? 1.0 : 0.0;
+    } else if (tid == 64) {
         for (int r = 0; r < 3; ++r) u[r] = Rnull[r * 3] * a.gravity[0] + Rnull[r * 3 + 1] * a.gravity[1] + Rnull[r * 3 + 2] * a.gravity[2];
         double uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
         for (int r = 0; r < 3; ++r) sv[r] = u[r] / uu;
+    } else if (tid == 128) {
         double dv[3] = {a.v_null[0] - a.v_new[0], a.v_null[1] - a.v_new[1], a.v_null[2] - a.v_new[2]};
         double dp[3] = {a.dt * a.v_null[0] + a.p_null[0] - a.p_new[0], a.dt * a.v_null[1] + a.p_null[1] - a.p_new[1], a.dt * a.v_null[2] + a.p_null[2] - a.p_new[2]};
         const double* g = a.gravity;
@@ -831,65 +835,56 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
         Phi[i] = (r == c ? 1.0 : 0.0) + F[i] + F2[i] / 2. + s / 6.;
     }
     __syncthreads();
+    // two patches of Phi that do not meet (each thread reads and writes only its own entries of Phi):
     if (tid < 9) {                                                              // Phi[:3,:3] = R_new R_null^T
         int r = tid / 3, c = tid % 3; double s = 0;
         for (int k = 0; k < 3; ++k) s += Rnew[r * 3 + k] * Rnull[c * 3 + k];
-        T[tid] = s;
-    }
-    __syncthreads();
-    if (tid < 9) Phi[(tid / 3) * N + tid % 3] = T[tid];
-    __syncthreads();
-    if (tid < 6) {                                                              // OC-KF corrections of rows 6..8 and 12..14
-        int blk = tid / 3, r = tid % 3;
-        int row = (blk == 0 ? 6 : 12) + r;
+        Phi[r * N + c] = s;
+    } else if (tid >= 64 && tid < 70) {                                         // OC-KF corrections of rows 6..8 and 12..14
+        const int t6 = tid - 64, blk = t6 / 3, r = t6 % 3;
+        const int row = (blk == 0 ? 6 : 12) + r;
         const double* wv = blk == 0 ? w1 : w2;
-        double Au = Phi[row * N] * u[0] + Phi[row * N + 1] * u[1] + Phi[row * N + 2] * u[2];
-        double d = Au - wv[r];
-        for (int c = 0; c < 3; ++c) T[tid * 3 + c] = Phi[row * N + c] - d * sv[c];
+        const double p0 = Phi[row * N], p1 = Phi[row * N + 1], p2 = Phi[row * N + 2];
+        const double Au = p0 * u[0] + p1 * u[1] + p2 * u[2];
+        const double d = Au - wv[r];
+        Phi[row * N] = p0 - d * sv[0]; Phi[row * N + 1] = p1 - d * sv[1]; Phi[row * N + 2] = p2 - d * sv[2];
     }
     __syncthreads();
-    if (tid < 6) {
-        int row = (tid / 3 == 0 ? 6 : 12) + tid % 3;
-        for (int c = 0; c < 3; ++c) Phi[row * N + c] = T[tid * 3 + c];
-    }
-    __syncthreads();
-    // Q = Phi G Qc G^T Phi^T dt : T = Phi G (21x12)
+    // three products with the finished Phi, side by side: T = Phi G (21 x 12, for Q = Phi G Qc G^T Phi^T dt), F2 = Phi P11, and in
+    // batched mode Q <- Phi PhiT (the frame's accumulated transition; Q is only a buffer here, the noise term is added below)
     for (int i = tid; i < N * 12; i += 256) {
         int r = i / 12, c = i - r * 12; double s = 0;
         for (int k = 0; k < N; ++k) s += Phi[r * N + k] * G[k * 12 + c];
         T[i] = s;
     }
-    __syncthreads();
-    for (int i = tid; i < N * N; i += 256) {
-        int r = i / N, c = i - r * N; double s = 0;
-        for (int k = 0; k < 12; ++k) s += T[r * 12 + k] * a.noise[k / 3] * T[c * 12 + k];
-        Q[i] = s * a.dt;
-    }
-    __syncthreads();
-    // P11 <- Phi P11 Phi^T + Q
     for (int i = tid; i < N * N; i += 256) {
         int r = i / N, c = i - r * N; double s = 0;
         if (P11s) { for (int k = 0; k < N; ++k) s += Phi[r * N + k] * P11s[k * N + c]; }
         else      { for (int k = 0; k < N; ++k) s += Phi[r * N + k] * a.P[(size_t)k * a.ld + c]; }
         F2[i] = s;                                                              // Phi P11
+        if (P11s) {
+            double s2 = 0;
+            for (int k = 0; k < N; ++k) s2 += Phi[r * N + k] * PhiT[k * N + c];
+            Q[i] = s2;
+        }
     }
     __syncthreads();
+    // P11 <- Phi P11 Phi^T + Q
     for (int i = tid; i < N * N; i += 256) {
-        int r = i / N, c = i - r * N; double s = 0;
+        int r = i / N, c = i - r * N; double s = 0, q = 0;
+        for (int k = 0; k < 12; ++k) q += T[r * 12 + k] * a.noise[k / 3] * T[c * 12 + k];
+        q = q * a.dt;
         for (int k = 0; k < N; ++k) s += F2[r * N + k] * Phi[c * N + k];
-        F[i] = s + Q[i];
+        F[i] = s + q;
     }
     __syncthreads();
     if (P11s) {
         // batched: symmetrised IMU block back to LDS ((P + P^T)/2 per sample, msckf.py:334-335), PhiT <- Phi PhiT
         for (int i = tid; i < N * N; i += 256) {
-            int r = i / N, c = i - r * N; double s = 0;
-            for (int k = 0; k < N; ++k) s += Phi[r * N + k] * PhiT[k * N + c];
-            F2[i] = s;
+            int r = i / N, c = i - r * N;
+            PhiT[i] = Q[i];
             P11s[i] = (F[r * N + c] + F[c * N + r]) / 2.;
         }
-        __syncthreads();
-        for (int i = tid; i < N * N; i += 256) PhiT[i] = F2[i];
         __syncthreads();
         return;
     }
