@@ -87,6 +87,21 @@ __device__ __forceinline__ double row16_sum_f64(double v)
     return v;
 }
 
+// sum over the 8 / 4 lanes of a team that is a fraction of a DPP row
+__device__ __forceinline__ double row8_sum_f64(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    return v;
+}
+__device__ __forceinline__ double quad_sum_f64(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    return v;
+}
+
 // ================================================================================================
 // Triangulation: one wavefront per feature, lane = view (obs j, camera c) with view = 2j + c.
 // ================================================================================================
@@ -324,6 +339,8 @@ struct FeatArgs {
     int n_list;                          // teams to run in this launch
     int team_doubles;                    // LDS doubles per team (wavefront teams: four per workgroup)
     unsigned long long* prof;            // optional [8] phase stamps of team 0 (diagnostic runs, AV_MSCKF_TIMING)
+    int compact;                         // > 0: the output rows hold ONLY the feature's own 6 M camera columns, `compact` doubles per row (the pruning phase of the
+                                         // device-resident filter: every candidate has the same two cameras, and the update gathers exactly these columns)
     int zero_fill;                       // 1: clear the full-width output rows first (columns of cameras the feature was not seen
                                          // from must read as zero); 0: the caller gathers only this feature's own camera columns
     // chained launches (batched filter): a feature triangulated by the triangulate_kernel launch just ahead on the same HIP
@@ -347,12 +364,20 @@ __host__ __device__ static inline size_t feature_lds_bytes(int Mx, int team = 25
 // TEAM = threads that cooperate on one feature: a whole 256-thread workgroup for long tracks, one wavefront (four
 // features per workgroup, no workgroup barriers) for tracks of at most 4 observations -- the two-camera prune of
 // msckf.py:714-800 produces ~300 two-observation features per stream and frame, which are latency- not work-bound.
-template <int TEAM>
+// MEM: the lanes also hand GLOBAL memory to each other across this point (the zero fill of the output rows must have landed before
+// other lanes overwrite parts of it).  Without it a team inside one wavefront only needs its LDS traffic ordered -- a wavefront's LDS
+// operations execute in issue order -- so the fence is wavefront-scoped and costs no s_waitcnt: the workgroup-scoped form drains
+// vmcnt as well, i.e. every phase boundary after the output rows were stored waited for those stores to be acknowledged.
+template <int TEAM, bool MEM = false>
 __device__ __forceinline__ void team_sync()
 {
-    if (TEAM == 256) __syncthreads();
-    else {      // workgroup-scope fences: the zero fill of the output rows must have landed before other lanes overwrite parts of it
+    if (TEAM == 256) {
+        if (MEM) __syncthreads();
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS hand-over only: no vmcnt(0), stores stay in flight
+    } else if (MEM) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -364,9 +389,10 @@ __device__ __forceinline__ void feature_body(const FeatArgs& a)
 {
     AV_FILTER_PRIO();
     extern __shared__ double sm_all[];
-    const int slot0 = TEAM == 256 ? (int)blockIdx.x : (int)(blockIdx.x * (256 / TEAM) + threadIdx.x / TEAM);
+    const int tpb = (int)blockDim.x / TEAM;               // teams per workgroup (the launch picks the workgroup size: 256 threads, 128 for 4-lane teams)
+    const int slot0 = TEAM == 256 ? (int)blockIdx.x : (int)(blockIdx.x * tpb + threadIdx.x / TEAM);
     if (a.n_list_dev) {                                   // device-side count: every team strides over the list (team-uniform trip count)
-        const int n = *a.n_list_dev, stride = (int)gridDim.x * (256 / TEAM);
+        const int n = *a.n_list_dev, stride = (int)gridDim.x * tpb;
         for (int slot = slot0; slot < n; slot += stride) { feature_one<TEAM>(a, slot, sm_all); team_sync<TEAM>(); }
         return;
     }
@@ -388,11 +414,11 @@ __device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, d
     const double* grav = a.stream_gravity ? a.stream_gravity + 3 * sidx : a.gravity;
     // 16-lane teams only ever see two-observation features (the pruning candidates: one observation from each of the two cameras
     // that go; launch_feature_kernel picks them for Mmax <= 2): M is a compile-time constant there and every loop below unrolls
-    const int o0 = a.obs_off[f], M = TEAM == 16 ? 2 : a.obs_off[f + 1] - o0;
+    const int o0 = a.obs_off[f], M = TEAM <= 16 ? 2 : a.obs_off[f + 1] - o0;
     const int R4 = 4 * M, C6 = 6 * M, K = R4 - 3;
-    const int Mx = TEAM == 16 ? 2 : a.Mmax;
+    const int Mx = TEAM <= 16 ? 2 : a.Mmax;
     const int tri = a.tri_idx ? a.tri_idx[f] : -1;
-    if (tri == -2 || (tri >= 0 && !a.tri_valid[tri]) || (a.valid && !a.valid[f]) || (TEAM == 16 && a.obs_off[f + 1] - o0 != 2)) {   // -2: failed check_motion on the host                  // whole team (uniform in f): triangulation failed, nothing to gate
+    if (tri == -2 || (tri >= 0 && !a.tri_valid[tri]) || (a.valid && !a.valid[f]) || (TEAM <= 16 && a.obs_off[f + 1] - o0 != 2)) {   // -2: failed check_motion on the host                  // whole team (uniform in f): triangulation failed, nothing to gate
         if (tid == 0) { a.gamma[f] = 0.0; a.pass[f] = 0; }
         return;
     }
@@ -542,7 +568,7 @@ __device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, d
             nrm = sqrt(red[0]);
             team_sync<TEAM>();
         } else {
-            nrm = sqrt(TEAM == 64 ? wave_sum_f64(part) : row16_sum_f64(part));
+            nrm = sqrt(TEAM == 64 ? wave_sum_f64(part) : (TEAM == 16 ? row16_sum_f64(part) : (TEAM == 8 ? row8_sum_f64(part) : quad_sum_f64(part))));
         }
         const double akk = Hf[k * 3 + k];
         const double alpha = akk >= 0 ? -nrm : nrm;
@@ -582,7 +608,7 @@ __device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, d
                 const int rI = i / a.ld, c = i - rI * a.ld;
                 Hout[(size_t)(row0 + rI) * a.ld + c] = 0.0;
             }
-            team_sync<TEAM>();
+            team_sync<TEAM, true>();
         }
         // Q^T H_x = H2 H1 H0 H_x column by column: with d_k = u_k^T col (four products: the column has four non-zeros),
         //   alpha0 = tau0 d0,  alpha1 = tau1 (d1 - alpha0 u1.u0),  alpha2 = tau2 (d2 - alpha0 u2.u0 - alpha1 u2.u1)
@@ -611,7 +637,8 @@ __device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, d
             const int rI = i / C6, c = i - rI * C6, row = 3 + rI, j = c / 6;
             double v = (row >> 2) == j ? Hb[row * 6 + (c - 6 * j)] : 0.0;
             v -= al[c] * Hf[row * 3] + al[C6 + c] * Hf[row * 3 + 1] + al[2 * C6 + c] * Hf[row * 3 + 2];
-            Hout[(size_t)(row0 + rI) * a.ld + IMU_DIM + 6 * cidx[j] + (c - 6 * j)] = v;
+            if (a.compact > 0) Hout[(size_t)(row0 + rI) * a.compact + c] = v;
+            else Hout[(size_t)(row0 + rI) * a.ld + IMU_DIM + 6 * cidx[j] + (c - 6 * j)] = v;
         }
         for (int i = tid; i < K; i += TEAM) rout[row0 + i] = rr[3 + i];
     }
@@ -626,7 +653,7 @@ __device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, d
     // rank-1 update.  One barrier per column, no square roots, no separate substitution pass (the single-thread forward
     // solve used to be half of this kernel's time on long tracks).
     double* wv = rr + 3;
-    constexpr int GX = TEAM == 256 ? 16 : (TEAM == 64 ? 8 : 4), GY = TEAM / GX;
+    constexpr int GX = TEAM == 256 ? 16 : (TEAM == 64 ? 8 : (TEAM == 4 ? 2 : 4)), GY = TEAM / GX;
     const int tx = tid % GX, ty = tid / GX;
     double g = 0;
     if (TEAM == 256 && K > 16) {
@@ -739,6 +766,14 @@ template <int TEAM> __global__ __launch_bounds__(256) void feature_kernel(FeatAr
 template <> __global__ __launch_bounds__(256) void feature_kernel<256>(FeatArgs a) { feature_body<256>(a); }
 template <> __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(256) void feature_kernel<64>(FeatArgs a) { feature_body<64>(a); }
 template <> __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(256) void feature_kernel<16>(FeatArgs a) { feature_body<16>(a); }
+// A/B builds of the 16-lane kernel at higher occupancy (PMC, round 4: 73 % of its wave cycles wait on memory, 10 % issue VALU): 96 and 80 registers
+__global__ __attribute__((amdgpu_waves_per_eu(2, 3))) __launch_bounds__(256) void feature_kernel16_w3(FeatArgs a) { feature_body<16>(a); }
+// eight and four lanes per two-observation feature (8 / 16 features per wavefront): the Jacobian phase keeps 2 lanes of a team busy and the
+// gate-matrix blocks 4, whatever the team size -- smaller teams waste fewer lanes there and take more rounds in the later phases
+__global__ __attribute__((amdgpu_waves_per_eu(2, 3))) __launch_bounds__(256) void feature_kernel8(FeatArgs a) { feature_body<8>(a); }
+__global__ __attribute__((amdgpu_waves_per_eu(2, 3))) __launch_bounds__(256) void feature_kernel4(FeatArgs a) { feature_body<4>(a); }
+__global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(256) void feature_kernel16_w5(FeatArgs a) { feature_body<16>(a); }
+__global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(256) void feature_kernel16_w6(FeatArgs a) { feature_body<16>(a); }
 
 static int msckf_lds_opt_in();       // raises the dynamic-LDS limit of every kernel below once per process
 
@@ -781,9 +816,15 @@ struct PropArgs {
 // and the transition matrices are accumulated into PhiT, so the cross block P12 <- Phi P12 is applied ONCE per frame
 // with the product of the frame's transition matrices instead of once per IMU sample (same map; ten passes over the
 // 21 x 6N block in global memory become one).
-__device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s = nullptr, double* PhiT = nullptr)
+constexpr int PROP_LDS_DOUBLES = 5 * IMU_DIM * IMU_DIM + IMU_DIM * 12;      // F, F2, Phi, T, Q, G
+// EXT: the six work matrices live in `ext` (PROP_LDS_DOUBLES doubles of LDS the caller also uses for something else at other times)
+template <bool EXT = false>
+__device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s = nullptr, double* PhiT = nullptr, double* ext = nullptr)
 {
-    __shared__ double F[IMU_DIM * IMU_DIM], F2[IMU_DIM * IMU_DIM], Phi[IMU_DIM * IMU_DIM], G[IMU_DIM * 12], T[IMU_DIM * IMU_DIM], Q[IMU_DIM * IMU_DIM];
+    __shared__ double own[EXT ? 1 : PROP_LDS_DOUBLES];
+    double* const base = EXT ? ext : own;
+    double* const F = base, * const F2 = F + IMU_DIM * IMU_DIM, * const Phi = F2 + IMU_DIM * IMU_DIM, * const T = Phi + IMU_DIM * IMU_DIM,
+          * const Q = T + IMU_DIM * IMU_DIM, * const G = Q + IMU_DIM * IMU_DIM;
     __shared__ double Rwi[9], Rnull[9], Rnew[9], u[3], sv[3], w1[3], w2[3];
     const int tid = threadIdx.x;
     const int N = IMU_DIM;
@@ -1053,10 +1094,42 @@ struct UpdArgs {
     int mode;                                    // batched back end: 0 = Cholesky pipeline, 1 = information form (upd_info_kernel)
     int kdir;                                    // batched back end: > 0 = rows kept (no QR compression: the stacked rows come in chunks), 0 = upd_k(m, nc)
     int round;                                   // batched back end: chunk number of a sequential update (> 0: residual minus H dx so far, dx accumulates)
+    int hld;                                     // batched back end: > 0 = Hsrc rows are COMPACT, hld doubles per row, column q of the row is state column cols[q] (FeatArgs::compact)
     int* status;                                 // batched back end: the stream's entry of StackArgs::stacked (NULL: single filter); a factorisation that meets a
                                                  // non-positive or non-finite pivot writes UPD_BAD_PIVOT there and turns the update into a no-op
 };
 constexpr int UPD_BAD_PIVOT = -2;
+
+// The batched kernels read their UpdArgs from an array in memory, and a pointer that arrives that way is GENERIC to the compiler: every
+// access through it becomes a FLAT load / store, which takes the slower flat path and counts on lgkmcnt (the LDS counter) as well as
+// vmcnt.  UpdArgsG is the same record with its pointers typed as global memory (address space 1: global_load / global_store); the
+// kernels below work on that view, their shared bodies are templates over the record type (dk_prune keeps its UpdArgs in LDS).
+template <typename T> using av_gptr = T __attribute__((address_space(1)))*;
+struct UpdArgsG {
+    av_gptr<double> P; int n, ld;
+    av_gptr<const double> Hsrc; av_gptr<const double> rsrc;
+    av_gptr<const int> blk_row; av_gptr<const int> blk_len; int n_blk;
+    av_gptr<double> W; int ldt;
+    av_gptr<const int> cols; int nc;
+    av_gptr<unsigned long long> prof;
+    av_gptr<double> T; av_gptr<double> Kt; av_gptr<double> Pn; av_gptr<double> dx;
+    double obs_noise; int m;
+    av_gptr<double> Sbuf;
+    int mode, kdir, round, hld;
+    av_gptr<int> status;
+};
+__device__ __forceinline__ UpdArgsG upd_load(const UpdArgs* __restrict__ arr, int i)
+{
+    const UpdArgs a = arr[i];
+    UpdArgsG g;
+    g.P = (av_gptr<double>)a.P; g.n = a.n; g.ld = a.ld; g.Hsrc = (av_gptr<const double>)a.Hsrc; g.rsrc = (av_gptr<const double>)a.rsrc;
+    g.blk_row = (av_gptr<const int>)a.blk_row; g.blk_len = (av_gptr<const int>)a.blk_len; g.n_blk = a.n_blk;
+    g.W = (av_gptr<double>)a.W; g.ldt = a.ldt; g.cols = (av_gptr<const int>)a.cols; g.nc = a.nc; g.prof = (av_gptr<unsigned long long>)a.prof;
+    g.T = (av_gptr<double>)a.T; g.Kt = (av_gptr<double>)a.Kt; g.Pn = (av_gptr<double>)a.Pn; g.dx = (av_gptr<double>)a.dx;
+    g.obs_noise = a.obs_noise; g.m = a.m; g.Sbuf = (av_gptr<double>)a.Sbuf; g.mode = a.mode; g.kdir = a.kdir; g.round = a.round; g.hld = a.hld;
+    g.status = (av_gptr<int>)a.status;
+    return g;
+}
 
 constexpr int UT = 1024;
 
@@ -1673,34 +1746,62 @@ __device__ __forceinline__ void update_back(const UpdArgs& a)
 // ================================================================================================
 constexpr int GT = 64, GQ = 16, GP = GT + 4;      // tile edge, panel depth, LDS pitch in doubles (16-B aligned rows)
 
+// Pointers that arrive inside a struct read from memory (UpdArgs) are generic to the compiler: it emits FLAT loads, which count on
+// lgkmcnt as well as vmcnt -- an LDS-only barrier would wait for them.  These casts say "global memory" (global_load: vmcnt only).
+typedef const double __attribute__((address_space(1)))* gcd_ptr;
+typedef const int __attribute__((address_space(1)))* gci_ptr;
+#define AV_GD(p) ((gcd_ptr)(p))
+#define AV_GI(p) ((gci_ptr)(p))
+
+// Workgroup barrier for LDS hand-overs only: the LDS writes of this wavefront are done (lgkmcnt(0)) and every wavefront has arrived.
+// __syncthreads() also drains vmcnt -- every global load or store in flight has to come back first -- which is what makes a
+// register-prefetched panel loop pointless: the loads issued for the NEXT panel would be waited for at THIS panel's barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 64 x 64 output tile, panels of GQ: the next panel's operands are fetched into registers while the current one is multiplied out of
+// LDS (two LDS buffers, one barrier per panel).  The un-pipelined form (load, barrier, multiply, barrier) paid one full global-memory
+// latency per panel -- PMC, round 4: the tile kernels waited 77-79 % of their wave cycles and issued VALU in 9 %.
+// The caller separates consecutive calls by a barrier.
 template <typename FA, typename FB>
 __device__ __forceinline__ void gemm_tile64(int Q, int r0, int c0, FA loadA, FB loadB, double (&acc)[4][4])
 {
-    __shared__ __attribute__((aligned(16))) double pa[GQ * GP], pb[GQ * GP];
+    __shared__ __attribute__((aligned(16))) double pa[2][GQ * GP], pb[2][GQ * GP];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-    for (int q0 = 0; q0 < Q; q0 += GQ) {
-        __syncthreads();
+    double ra[4], rb[4];
+    auto fetch = [&](int q0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int idx = tid + 256 * u, q = idx >> 6, e = idx & 63;
             const bool in = q0 + q < Q;
-            pa[q * GP + e] = in ? loadA(q0 + q, r0 + e) : 0.0;
-            pb[q * GP + e] = in ? loadB(q0 + q, c0 + e) : 0.0;
+            ra[u] = in ? loadA(q0 + q, r0 + e) : 0.0;
+            rb[u] = in ? loadB(q0 + q, c0 + e) : 0.0;
         }
-        __syncthreads();
+    };
+    fetch(0);
+    int buf = 0;
+    for (int q0 = 0; q0 < Q; q0 += GQ) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 256 * u, q = idx >> 6, e = idx & 63;
+            pa[buf][q * GP + e] = ra[u];
+            pb[buf][q * GP + e] = rb[u];
+        }
+        if (q0 + GQ < Q) fetch(q0 + GQ);                   // in flight during the products below
+        lds_barrier();
 #pragma unroll
         for (int q = 0; q < GQ; ++q) {
-            const av_d4 av = *reinterpret_cast<const av_d4*>(&pa[q * GP + 4 * ty]);
-            const av_d4 bv = *reinterpret_cast<const av_d4*>(&pb[q * GP + 4 * tx]);
+            const av_d4 av = *reinterpret_cast<const av_d4*>(&pa[buf][q * GP + 4 * ty]);
+            const av_d4 bv = *reinterpret_cast<const av_d4*>(&pb[buf][q * GP + 4 * tx]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(av[i], bv[j], acc[i][j]);
         }
+        buf ^= 1;
     }
 }
 
@@ -1708,7 +1809,7 @@ __device__ __forceinline__ void gemm_tile64(int Q, int r0, int c0, FA loadA, FB 
 __global__ __launch_bounds__(256) void upd_tt_kernel(const UpdArgs* __restrict__ arr, int tiles_k)
 {
     AV_FILTER_PRIO();
-    const UpdArgs a = arr[blockIdx.y];
+    const UpdArgsG a = upd_load(arr, blockIdx.y);
     if (a.m <= 0 || a.mode != 0) return;
     const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc)), n = a.n;
     const int r0 = (blockIdx.x / tiles_k) * GT, c0 = (blockIdx.x % tiles_k) * GT;      // rows: state index, columns: stacked row
@@ -1716,14 +1817,14 @@ __global__ __launch_bounds__(256) void upd_tt_kernel(const UpdArgs* __restrict__
     const size_t ldt = a.ldt;
     double acc[4][4];
     gemm_tile64(a.nc, r0, c0,
-                [&](int q, int c) { return c < n ? a.P[(size_t)a.cols[q] * a.ld + c] : 0.0; },
-                [&](int q, int r) { return r < k ? a.W[(size_t)q * ldt + r] : 0.0; }, acc);
+                [&](int q, int c) { return c < n ? AV_GD(a.P)[(size_t)AV_GI(a.cols)[q] * a.ld + c] : 0.0; },
+                [&](int q, int r) { return r < k ? AV_GD(a.W)[(size_t)q * ldt + r] : 0.0; }, acc);
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = r0 + 4 * ty + i;
         // columns at or beyond k (rounded up to the 4-wide store) belong to nobody: a 64-wide tile may reach past the row pitch
-        if (c < n && c0 + 4 * tx < k) { av_d4 o = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]}; *reinterpret_cast<av_d4*>(a.T + (size_t)c * a.ld + c0 + 4 * tx) = o; }
+        if (c < n && c0 + 4 * tx < k) { av_d4 o = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]}; *(av_gptr<av_d4>)(a.T + (size_t)c * a.ld + c0 + 4 * tx) = o; }
     }
 }
 
@@ -1731,7 +1832,7 @@ __global__ __launch_bounds__(256) void upd_tt_kernel(const UpdArgs* __restrict__
 __global__ __launch_bounds__(256) void upd_s_kernel(const UpdArgs* __restrict__ arr)
 {
     AV_FILTER_PRIO();
-    const UpdArgs a = arr[blockIdx.y];
+    const UpdArgsG a = upd_load(arr, blockIdx.y);
     if (a.m <= 0 || a.mode != 0) return;
     const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
     int tr = (int)((sqrtf(8.f * blockIdx.x + 1.f) - 1.f) * 0.5f);              // triangular tile index -> (tr, tc), tc <= tr
@@ -1743,8 +1844,8 @@ __global__ __launch_bounds__(256) void upd_s_kernel(const UpdArgs* __restrict__ 
     const size_t ldt = a.ldt;
     double acc[4][4];
     gemm_tile64(a.nc, r0, c0,
-                [&](int q, int r) { return r < k ? a.T[(size_t)a.cols[q] * a.ld + r] : 0.0; },
-                [&](int q, int c) { return c < k ? a.W[(size_t)q * ldt + c] : 0.0; }, acc);
+                [&](int q, int r) { return r < k ? AV_GD(a.T)[(size_t)AV_GI(a.cols)[q] * a.ld + r] : 0.0; },
+                [&](int q, int c) { return c < k ? AV_GD(a.W)[(size_t)q * ldt + c] : 0.0; }, acc);
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1753,7 +1854,7 @@ __global__ __launch_bounds__(256) void upd_s_kernel(const UpdArgs* __restrict__ 
             av_d4 o = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (c0 + 4 * tx + j == r) o[j] += a.obs_noise;
-            *reinterpret_cast<av_d4*>(a.Sbuf + (size_t)r * a.ld + c0 + 4 * tx) = o;       // k <= 144 < ld: the 4-wide store stays inside the row
+            *(av_gptr<av_d4>)(a.Sbuf + (size_t)r * a.ld + c0 + 4 * tx) = o;       // k <= 144 < ld: the 4-wide store stays inside the row
         }
     }
 }
@@ -1838,17 +1939,21 @@ __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict
 {
     AV_FILTER_PRIO();
     extern __shared__ double Lp[];
-    const UpdArgs a = arr[blockIdx.x];
+    const UpdArgsG a = upd_load(arr, blockIdx.x);
     if (a.m <= 0 || a.mode != 0) return;
     const int tid = threadIdx.x;
     const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
     auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
+    auto stamp = [&](int i) { if (a.prof && tid == 0) a.prof[i] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(8);
     for (int e = tid; e < k * k; e += 256) {
         const int r = e / k, c = e - r * k;
         if (c <= r) at(r, c) = a.Sbuf[(size_t)r * a.ld + c];
     }
     __syncthreads();
+    stamp(9);
     const bool ok = chol_packed_lds(Lp, k, tid);
+    stamp(10);
     if (!ok && tid == 0 && a.status) *a.status = UPD_BAD_PIVOT;      // S = H P H^T + s^2 I not positive definite: the covariance is corrupt
     // L is written as a symmetric matrix: the substitution kernel reads eight consecutive rows of one COLUMN of L per step,
     // which the mirrored upper triangle holds contiguously (one 64-byte scalar load instead of eight).
@@ -1858,6 +1963,8 @@ __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict
         const int r = e / k, c = e - r * k;
         a.Sbuf[(size_t)r * a.ld + c] = ok ? (c <= r ? at(r, c) : at(c, r)) : (r == c ? 1e150 : 0.0);
     }
+    stamp(11);
+    if (a.prof && tid == 0) a.prof[12] = (unsigned long long)k;
 }
 
 // Y = L^-1 [T | r_thin]: one LANE per right-hand side (column c < n is row c of T^T, c == n is r_thin), 64 right-hand sides
@@ -1867,7 +1974,7 @@ __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict
 __global__ __launch_bounds__(64) void upd_fsolve_kernel(const UpdArgs* __restrict__ arr)
 {
     AV_FILTER_PRIO();
-    const UpdArgs a = arr[blockIdx.y];
+    const UpdArgsG a = upd_load(arr, blockIdx.y);
     if (a.m <= 0 || a.mode != 0) return;
     const int n = a.n, nc = a.nc, k = (a.kdir > 0 ? a.kdir : upd_k(a.m, nc));
     if ((int)blockIdx.x * 64 > n) return;
@@ -1876,9 +1983,9 @@ __global__ __launch_bounds__(64) void upd_fsolve_kernel(const UpdArgs* __restric
     typedef const double __attribute__((address_space(4)))* scalar_ptr;
     scalar_ptr L = (scalar_ptr)(a.Sbuf);
     const int ld = a.ld;
-    double* rcol = a.W + (size_t)nc * a.ldt;
-    const double* src = (act && c < n) ? a.T + (size_t)c * ld : rcol;
-    double* y = (act && c < n) ? a.Kt + c : rcol;
+    const av_gptr<double> rcol = a.W + (size_t)nc * a.ldt;
+    const av_gptr<const double> src = (act && c < n) ? a.T + (size_t)c * ld : rcol;
+    const av_gptr<double> y = (act && c < n) ? a.Kt + c : rcol;
     const size_t st_ = (act && c < n) ? (size_t)ld : 1;
     for (int i0 = 0; i0 < k; i0 += 8) {
         double acc[8];
@@ -1913,7 +2020,7 @@ __global__ __launch_bounds__(64) void upd_fsolve_kernel(const UpdArgs* __restric
 __global__ __launch_bounds__(256) void upd_p_kernel(const UpdArgs* __restrict__ arr)
 {
     AV_FILTER_PRIO();
-    const UpdArgs a = arr[blockIdx.y];
+    const UpdArgsG a = upd_load(arr, blockIdx.y);
     if (a.m <= 0 || a.mode != 0) return;
     const int n = a.n, k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
     int tr = (int)((sqrtf(8.f * blockIdx.x + 1.f) - 1.f) * 0.5f);
@@ -1924,10 +2031,10 @@ __global__ __launch_bounds__(256) void upd_p_kernel(const UpdArgs* __restrict__ 
     if (r0 >= n) return;
     double t[4][4];
     gemm_tile64(k, r0, c0,
-                [&](int q, int r) { return r < n ? a.Kt[(size_t)q * a.ld + r] : 0.0; },
-                [&](int q, int c) { return c < n ? a.Kt[(size_t)q * a.ld + c] : 0.0; }, t);
+                [&](int q, int r) { return r < n ? AV_GD(a.Kt)[(size_t)q * a.ld + r] : 0.0; },
+                [&](int q, int c) { return c < n ? AV_GD(a.Kt)[(size_t)q * a.ld + c] : 0.0; }, t);
     if (blockIdx.x == 0) {                                   // delta_x = Y^T y_r, by the stream's first tile
-        const double* rcol = a.W + (size_t)a.nc * a.ldt;
+        const auto rcol = a.W + (size_t)a.nc * a.ldt;
         for (int c = threadIdx.x; c < n; c += 256) {
             double sacc = 0;
 #pragma unroll 8
@@ -1983,17 +2090,17 @@ static inline size_t upd_info_lds(int nc, int n, int m)
     return sizeof(double) * ((size_t)nc * nc + nc + (size_t)nc * (n + 1) + (size_t)nc * (nc + n + 2) + (size_t)INFO_CH * (INFO_NC + 1)) + sizeof(int) * ((size_t)m + 2) + 64;
 }
 
-__device__ __forceinline__ void upd_info_body(const UpdArgs& a, double* Li);
+template <typename UA> __device__ __forceinline__ void upd_info_body(const UA& a, double* Li);
 __global__ __launch_bounds__(256) void upd_info_kernel(const UpdArgs* __restrict__ arr)
 {
     AV_FILTER_PRIO();
     extern __shared__ double Li_dyn[];
-    const UpdArgs a = arr[blockIdx.x];
+    const UpdArgsG a = upd_load(arr, blockIdx.x);
     if (a.m <= 0 || a.mode != 1) return;
     upd_info_body(a, Li_dyn);
 }
 // (also called by the fused pruning kernel of the device-resident filter, msckf_dev.inc: dk_prune)
-__device__ __forceinline__ void upd_info_body(const UpdArgs& a, double* Li)
+template <typename UA> __device__ __forceinline__ void upd_info_body(const UA& a, double* Li)
 {
     const int tid = threadIdx.x, n = a.n, nc = a.nc, nb = a.n_blk;
     double* A = Li;                          // [nc][nc]
@@ -2002,6 +2109,8 @@ __device__ __forceinline__ void upd_info_body(const UpdArgs& a, double* Li)
     double* G = Pc + (size_t)nc * (n + 1);   // [nc][W]     augmented [M | F | b], W = nc + n + 1 (+1 pad)
     const int PW_ = n + 1, W = nc + n + 2;
     __shared__ int piv_row;
+    auto stamp = [&](int i) { if (a.prof && tid == 0) a.prof[i] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
     // 1. A = Hc^T Hc (upper triangle, then mirrored), b = Hc^T r.  The stacked rows are staged through LDS in chunks of INFO_CH
     //    rows x (nc + 1) values by all 256 threads (the next chunk's loads are in flight while this one is summed); a thread
     //    per entry of A / b then accumulates over the chunk.  Row map: stacked row i -> row of the feature-block buffer.
@@ -2026,6 +2135,7 @@ __device__ __forceinline__ void upd_info_body(const UpdArgs& a, double* Li)
         }
         __syncthreads();
     }
+    stamp(1);
     {
         const int m = a.m, cw = nc + 1;
         // entries: the nc (nc + 1) / 2 pairs (r, c <= r) of A, then the nc entries of b -- at most 324 for nc = 24: two per thread
@@ -2050,27 +2160,29 @@ __device__ __forceinline__ void upd_info_body(const UpdArgs& a, double* Li)
             for (int u = 0; u < PER; ++u) {
                 const int idx = tid + 256 * u, rr = idx / cw, cc = idx - rr * cw;
                 stage[u] = 0.0;
-                if (rr < INFO_CH && base + rr < m) { const int sr = srow[base + rr]; stage[u] = cc < nc ? a.Hsrc[(size_t)sr * a.ld + a.cols[cc]] : a.rsrc[sr]; }
+                if (rr < INFO_CH && base + rr < m) { const int sr = srow[base + rr]; stage[u] = cc < nc ? (a.hld > 0 ? a.Hsrc[(size_t)sr * a.hld + cc] : a.Hsrc[(size_t)sr * a.ld + a.cols[cc]]) : a.rsrc[sr]; }
             }
         };
         fetch(0);
         for (int base = 0; base < m; base += INFO_CH) {
 #pragma unroll
             for (int u = 0; u < PER; ++u) { const int idx = tid + 256 * u; if (idx < INFO_CH * cw) chunk[idx] = stage[u]; }
-            __syncthreads();
+            lds_barrier();                                            // (LDS-only barriers: __syncthreads() would wait for the prefetch below)
             if (base + INFO_CH < m) fetch(base + INFO_CH);            // next chunk's loads overlap this chunk's sums
             const int rows = min(INFO_CH, m - base);
 #pragma unroll
             for (int v = 0; v < 2; ++v)
                 if (act[v]) for (int rr = 0; rr < rows; ++rr) acc[v] = __builtin_fma(chunk[rr * cw + ei[v]], chunk[rr * cw + ej[v]], acc[v]);
-            __syncthreads();
+            lds_barrier();
         }
 #pragma unroll
         for (int v = 0; v < 2; ++v)
             if (act[v]) { if (ej[v] == nc) bv[ei[v]] = acc[v]; else { A[ei[v] * nc + ej[v]] = acc[v]; A[ej[v] * nc + ei[v]] = acc[v]; } }
     }
+    stamp(2);
     for (int e = tid; e < nc * n; e += 256) { const int q = e / n, c = e - q * n; Pc[q * PW_ + c] = a.P[(size_t)a.cols[q] * a.ld + c]; }
     __syncthreads();
+    stamp(3);
     // 2. F = A Pc (nc x n);  G = [F[:, cols] + s^2 I | F | b]
     for (int e = tid; e < nc * n; e += 256) {
         const int i = e / n, c = e - i * n;
@@ -2082,6 +2194,7 @@ __device__ __forceinline__ void upd_info_body(const UpdArgs& a, double* Li)
     __syncthreads();
     for (int e = tid; e < nc * nc; e += 256) { const int i = e / nc, j = e - i * nc; G[i * W + j] = G[i * W + nc + a.cols[j]] + (i == j ? a.obs_noise : 0.0); }
     __syncthreads();
+    stamp(4);
     // 3. Gauss-Jordan with partial pivoting on the augmented rows: afterwards G[:, nc:] = M^-1 [F | b] (scaled by the pivots)
     for (int p = 0; p < nc; ++p) {
         if (tid == 0) {
@@ -2101,8 +2214,10 @@ __device__ __forceinline__ void upd_info_body(const UpdArgs& a, double* Li)
         }
         __syncthreads();
     }
+    stamp(5);
     for (int e = tid; e < nc * (n + 1); e += 256) { const int i = e / (n + 1), c = e - i * (n + 1); G[i * W + nc + c] /= G[i * W + i]; }
     __syncthreads();
+    stamp(6);
     // 4. dx = P[:,c] X_b;   P <- sym(P - P[:,c] X): a thread per pair (r, c <= r), in place
     const double* X = G + nc;                // X[q][c] = G[q*W + nc + c], c < n; X_b = column n
     for (int c = tid; c < n; c += 256) {
@@ -2124,6 +2239,7 @@ __device__ __forceinline__ void upd_info_body(const UpdArgs& a, double* Li)
         a.P[(size_t)r * a.ld + c] = v;
         a.P[(size_t)c * a.ld + r] = v;
     }
+    stamp(7);
 }
 
 __global__ __launch_bounds__(UT) void update_front_kernel(UpdArgs a) { update_front(a); }
@@ -2140,7 +2256,7 @@ __global__ __launch_bounds__(UT) void update_front_batch_kernel(const UpdArgs* _
 __global__ __launch_bounds__(256) void upd_gather_kernel(const UpdArgs* __restrict__ arr)
 {
     AV_FILTER_PRIO();
-    const UpdArgs a = arr[blockIdx.x];
+    const UpdArgsG a = upd_load(arr, blockIdx.x);
     if (a.m <= 0 || a.mode != 0 || (a.kdir <= 0 && upd_compress(a.m, a.nc))) return;
     __shared__ int srow[256], bstart[256];
     const int tid = threadIdx.x, m = a.m, nc = a.nc, nb = a.n_blk;        // m <= 144, every block has at least one row
@@ -2153,7 +2269,7 @@ __global__ __launch_bounds__(256) void upd_gather_kernel(const UpdArgs* __restri
         const int q = i / m, row = i - q * m;
         a.W[(size_t)q * ldt + row] = a.Hsrc[(size_t)srow[row] * a.ld + a.cols[q]];
     }
-    double* rcol = a.W + (size_t)nc * ldt;
+    const auto rcol = a.W + (size_t)nc * ldt;
     // later chunks of a sequential update see the state correction of the earlier ones: r' = r - H dx (the batch update of
     // [H0; H1] equals the update with H0 followed by the update with H1 on (P1, r1 - H1 dx1); dx is injected once, at the end)
     for (int row = tid; row < m; row += 256) {
@@ -2178,22 +2294,22 @@ __global__ __launch_bounds__(256) void upd_gather_kernel(const UpdArgs* __restri
 //   upd_gram_chol_kernel  sum of the slabs -> bordered Cholesky in LDS -> [F | f] written as the k = n_c rows of W
 // ================================================================================================
 constexpr int GRAM_CHUNK = 256;
-__device__ __forceinline__ bool upd_front_needed(const UpdArgs& a) { return a.m > 0 && a.mode == 0 && a.kdir <= 0 && upd_compress(a.m, a.nc); }
+template <typename UA> __device__ __forceinline__ bool upd_front_needed(const UA& a) { return a.m > 0 && a.mode == 0 && a.kdir <= 0 && upd_compress(a.m, a.nc); }
 
 // (n_list_dev != NULL: the list was written on the device -- upd_stack_kernel -- and holds *n_list_dev streams; the workgroups
 //  stride over it.  NULL: one workgroup per listed stream, as launched by the host.)
-__device__ __forceinline__ void upd_rowmap_one(const UpdArgs& a);
+template <typename UA> __device__ __forceinline__ void upd_rowmap_one(const UA& a);
 __global__ __launch_bounds__(256) void upd_rowmap_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list, const int* __restrict__ n_list_dev)
 {
     AV_FILTER_PRIO();
-    if (n_list_dev) { const int n = *n_list_dev; for (int l = blockIdx.x; l < n; l += gridDim.x) { upd_rowmap_one(arr[list[l]]); __syncthreads(); } return; }
-    upd_rowmap_one(arr[list[blockIdx.x]]);
+    if (n_list_dev) { const int n = *n_list_dev; for (int l = blockIdx.x; l < n; l += gridDim.x) { upd_rowmap_one(upd_load(arr, list[l])); __syncthreads(); } return; }
+    upd_rowmap_one(upd_load(arr, list[blockIdx.x]));
 }
-__device__ __forceinline__ void upd_rowmap_one(const UpdArgs& a)
+template <typename UA> __device__ __forceinline__ void upd_rowmap_one(const UA& a)
 {
     if (!upd_front_needed(a)) return;
     __shared__ int wsum[4], carry;
-    int* srcrow = reinterpret_cast<int*>(a.Kt);
+    const auto srcrow = (av_gptr<int>)(a.Kt);
     const int tid = threadIdx.x, nb = a.n_blk;
     if (tid == 0) carry = 0;
     __syncthreads();
@@ -2216,14 +2332,14 @@ __device__ __forceinline__ void upd_rowmap_one(const UpdArgs& a)
 }
 
 // slab (chunk y) of the Gram matrix of G = [Hc | r] (m x (nc + 1)): tile x of the lower 64 x 64 tiles
-__device__ __forceinline__ void upd_gram_one(const UpdArgs& a);
+template <typename UA> __device__ __forceinline__ void upd_gram_one(const UA& a);
 __global__ __launch_bounds__(256) void upd_gram_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list, const int* __restrict__ n_list_dev)
 {
     AV_FILTER_PRIO();
-    if (n_list_dev) { const int n = *n_list_dev; for (int l = blockIdx.z; l < n; l += gridDim.z) { upd_gram_one(arr[list[l]]); __syncthreads(); } return; }
-    upd_gram_one(arr[list[blockIdx.z]]);
+    if (n_list_dev) { const int n = *n_list_dev; for (int l = blockIdx.z; l < n; l += gridDim.z) { upd_gram_one(upd_load(arr, list[l])); __syncthreads(); } return; }
+    upd_gram_one(upd_load(arr, list[blockIdx.z]));
 }
-__device__ __forceinline__ void upd_gram_one(const UpdArgs& a)
+template <typename UA> __device__ __forceinline__ void upd_gram_one(const UA& a)
 {
     if (!upd_front_needed(a)) return;
     const int m = a.m, nc = a.nc, k1 = nc + 1;
@@ -2236,15 +2352,15 @@ __device__ __forceinline__ void upd_gram_one(const UpdArgs& a)
     const int tc = blockIdx.x - tr * (tr + 1) / 2;
     const int r0 = tr * GT, c0 = tc * GT;
     if (r0 >= k1) return;
-    const int* srcrow = reinterpret_cast<const int*>(a.Kt) + row0;
+    const auto srcrow = (av_gptr<const int>)(a.Kt) + row0;
     auto elem = [&](int q, int c) -> double {            // G[row0 + q][c]
         if (c >= k1) return 0.0;
         const size_t sr = (size_t)srcrow[q];
-        return c < nc ? a.Hsrc[sr * a.ld + a.cols[c]] : a.rsrc[sr];
+        return c < nc ? AV_GD(a.Hsrc)[sr * a.ld + AV_GI(a.cols)[c]] : AV_GD(a.rsrc)[sr];
     };
     double acc[4][4];
     gemm_tile64(rows, r0, c0, elem, elem, acc);
-    double* slab = a.W + (size_t)blockIdx.y * k1 * k1;
+    const auto slab = a.W + (size_t)blockIdx.y * k1 * k1;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -2255,15 +2371,15 @@ __device__ __forceinline__ void upd_gram_one(const UpdArgs& a)
         }
 }
 
-__device__ __forceinline__ void upd_gram_chol_one(const UpdArgs& a, double* Lp);
+template <typename UA> __device__ __forceinline__ void upd_gram_chol_one(const UA& a, double* Lp);
 __global__ __launch_bounds__(256) void upd_gram_chol_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list, const int* __restrict__ n_list_dev)
 {
     AV_FILTER_PRIO();
     extern __shared__ double Lp_dyn[];
-    if (n_list_dev) { const int n = *n_list_dev; for (int l = blockIdx.x; l < n; l += gridDim.x) { upd_gram_chol_one(arr[list[l]], Lp_dyn); __syncthreads(); } return; }
-    upd_gram_chol_one(arr[list[blockIdx.x]], Lp_dyn);
+    if (n_list_dev) { const int n = *n_list_dev; for (int l = blockIdx.x; l < n; l += gridDim.x) { upd_gram_chol_one(upd_load(arr, list[l]), Lp_dyn); __syncthreads(); } return; }
+    upd_gram_chol_one(upd_load(arr, list[blockIdx.x]), Lp_dyn);
 }
-__device__ __forceinline__ void upd_gram_chol_one(const UpdArgs& a, double* Lp)
+template <typename UA> __device__ __forceinline__ void upd_gram_chol_one(const UA& a, double* Lp)
 {
     if (!upd_front_needed(a)) return;
     const int tid = threadIdx.x, m = a.m, nc = a.nc, k1 = nc + 1;
@@ -2298,7 +2414,7 @@ __device__ __forceinline__ void upd_gram_chol_one(const UpdArgs& a, double* Lp)
         const int q = e / nc, row = e - q * nc;
         a.W[(size_t)q * ldt + row] = (ok && row <= q) ? at(q, row) : 0.0;
     }
-    double* rcol = a.W + (size_t)nc * ldt;
+    const auto rcol = a.W + (size_t)nc * ldt;
     for (int row = tid; row < nc; row += 256) rcol[row] = ok ? at(nc, row) : 0.0;
 }
 // ================================================================================================
@@ -2329,6 +2445,7 @@ struct StackArgs {
     int* row_off_w; int* again_list; int* again_count;   //  gated without storage (row_off = -1): the stacked ones get compact offsets here and are listed to run again
     int* clist; int* clist_count;            // out: streams whose stacked rows exceed one back-end pass (compression kernels stride over this list)
     double* work;                            // [S][8] accumulators of av_msckf_batch_work: gate flops, update flops, reference-QR flops, gated, updates, rows
+    int hld;                                 // UpdArgs::hld of this phase's updates (0: dense rows)
     int no_info;                             // 1: this phase launches no information-form kernel (every stream takes the Cholesky back end)
 };
 __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
@@ -2430,7 +2547,7 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
     }
     for (int r = lane; r < a.rounds; r += 64) {
         UpdArgs u = b;
-        u.mode = mode; u.round = r; u.kdir = 0; u.nc = nc; u.cols = a.cols + (size_t)s * a.cols_stride; u.status = a.stacked + s;
+        u.mode = mode; u.round = r; u.kdir = 0; u.nc = nc; u.hld = a.hld; u.cols = a.cols + (size_t)s * a.cols_stride; u.status = a.stacked + s;
         u.blk_row = a.blk_row + i0; u.blk_len = a.blk_len + i0; u.n_blk = nb; u.m = (too_many || overflow) ? 0 : m;
         if (u.m > 0 && mode == 0 && a.compress) {
             if (r > 0) u.m = 0;
@@ -2462,7 +2579,8 @@ static int msckf_lds_opt_in()
 {
     static const int rc = [] {
         const int lim = 160 * 1024;
-        const void* fns[5] = {reinterpret_cast<const void*>(feature_kernel<16>), reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
+        const void* fns[7] = {reinterpret_cast<const void*>(feature_kernel8), reinterpret_cast<const void*>(feature_kernel4),
+                              reinterpret_cast<const void*>(feature_kernel<16>), reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
                               reinterpret_cast<const void*>(update_front_kernel), reinterpret_cast<const void*>(update_front_batch_kernel)};
         const void* fns2[5] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel),
                                reinterpret_cast<const void*>(upd_chol_kernel), reinterpret_cast<const void*>(upd_info_kernel),
