@@ -445,11 +445,58 @@ def test_batched_long_run_with_feature_table_compaction(cfg):
     bat.close()
 
 
+def test_overflow_pool_exhaustion_stops_the_stream_with_a_capacity_error(cfg, monkeypatch):
+    """The overflow pool is a capacity like the camera slots and the feature table: a stream that cannot get its rows stops with
+    AV_E_CAPACITY, loudly, and the other streams of the batch go on.  (AV_MSCKF_POOL_ROWS shrinks the pool for this test.)"""
+    from uav_airvision_amd import _native as N
+    from uav_airvision_amd.msckf_ops import BatchedMSCKF
+    from uav_airvision_amd.synth import SyntheticFeatureStream, feature_msg_t
+    monkeypatch.setenv('AV_MSCKF_POOL_ROWS', '64')
+    n_frames = 24
+    streams = [SyntheticFeatureStream(cfg, seed=91, n_frames=n_frames, n_features=150),
+               SyntheticFeatureStream(cfg, seed=92, n_frames=n_frames, n_features=40)]
+    S = len(streams)
+    bat = BatchedMSCKF(cfg, S, rows_cap=2048)
+    if not bat.device_resident():
+        bat.close(); pytest.skip('host-bookkeeping path (AV_MSCKF_STORE=host): no pool')
+    its = [iter(s.imu) for s in streams]
+    pend = [next(it, None) for it in its]
+    cap = 192
+    failed_at = None
+    for k in range(n_frames):
+        msgs = [s.frame(k) for s in streams]
+        if k == 17:
+            msgs[0] = feature_msg_t(msgs[0].timestamp, [])            # stream 0 loses ~130 long tracks at once: ~5 k rows
+        si, ts, gy, ac = [], [], [], []
+        for i, m in enumerate(msgs):
+            while pend[i] is not None and pend[i].timestamp <= m.timestamp:
+                si.append(i); ts.append(pend[i].timestamp); gy.append(pend[i].angular_velocity); ac.append(pend[i].linear_acceleration)
+                pend[i] = next(its[i], None)
+        if si:
+            bat.push_imu(si, ts, gy, ac)
+        ids = np.zeros((S, cap), np.int64); uv = np.zeros((S, cap, 4)); nf = np.zeros(S, np.int32)
+        for i, m in enumerate(msgs):
+            nf[i] = len(m.features)
+            for j, f in enumerate(m.features):
+                ids[i, j] = f.id; uv[i, j] = (f.u0, f.v0, f.u1, f.v1)
+        out = bat.step(ids, uv, nf, [m.timestamp for m in msgs])
+        if out[0, 0] < 0 and failed_at is None:
+            failed_at = k
+        if k > 2:
+            assert out[1, 0] == 1.0, k                                 # stream 1 keeps publishing
+    assert failed_at == 17, failed_at
+    code, msg = bat.stream_status(0)
+    assert code == N.AV_E_CAPACITY and 'pool' in msg, (code, msg)
+    assert bat.stream_status(1) == (0, '')
+    bat.close()
+
+
 def test_blank_frame_drops_every_track_at_once(cfg):
     """A blank / blurred frame: the feature message is empty, so every live track is lost in the same frame and the
     lost-feature candidates reserve far more rows than rows_cap (here ~3-4 k against 2048).  The reference handles any
-    number (msckf.py:614-676: gate in map order, stop after > 1500 stacked rows); the batch gates such a stream first
-    and stores only the stacked features second.  Must equal the numpy oracle on every frame, before, at and after."""
+    number (msckf.py:614-676: gate in map order, stop after > 1500 stacked rows); the device-resident batch gives such a
+    stream rows from the overflow pool all streams share (the host-bookkeeping path gates first and stores only the stacked
+    features second).  Must equal the numpy oracle on every frame, before, at and after."""
     from oracle.msckf_np import OracleMSCKF
     from uav_airvision_amd.msckf_ops import BatchedMSCKF
     from uav_airvision_amd.synth import SyntheticFeatureStream, feature_msg_t
@@ -492,7 +539,7 @@ def test_blank_frame_drops_every_track_at_once(cfg):
             err = max(np.abs(out[i, 2:5] - s.position).max(), np.abs(out[i, 5:9] - s.orientation).max(), np.abs(out[i, 9:12] - s.velocity).max())
             assert err < 1e-6, (k, i, err)
     c = bat.counters()
-    assert c['two_pass_streams'] >= 2, c                 # stream 0's blank frames really took the two-pass route
+    assert c['two_pass_streams'] >= 2, c                 # the blank frames really outgrew rows_cap (pool / two-pass route taken)
     assert c['devbuf_growths'] == 0, c                   # nothing was reallocated after the first step's reserve
     for i in range(S):
         P, Po = bat.get_cov(i), oras[i].state_cov

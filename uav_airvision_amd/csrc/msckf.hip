@@ -766,7 +766,9 @@ template <int TEAM> __global__ __launch_bounds__(256) void feature_kernel(FeatAr
 template <> __global__ __launch_bounds__(256) void feature_kernel<256>(FeatArgs a) { feature_body<256>(a); }
 template <> __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(256) void feature_kernel<64>(FeatArgs a) { feature_body<64>(a); }
 template <> __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(256) void feature_kernel<16>(FeatArgs a) { feature_body<16>(a); }
-// A/B builds of the 16-lane kernel at higher occupancy (PMC, round 4: 73 % of its wave cycles wait on memory, 10 % issue VALU): 96 and 80 registers
+// The device-resident filter's build of the 16-lane kernel: 207 registers, nothing spilled, two waves per SIMD.  Measured per 2,048-stream
+// launch (round 4, profiles/r04/README.md): 564 us, against 688 us at 128 registers (256 B of scratch per lane), 814 at 96, 920 at 80 --
+// PMC showed 73 % of the wave cycles waiting on memory, and the spill traffic was part of what they waited for.
 __global__ __attribute__((amdgpu_waves_per_eu(2, 3))) __launch_bounds__(256) void feature_kernel16_w3(FeatArgs a) { feature_body<16>(a); }
 // eight and four lanes per two-observation feature (8 / 16 features per wavefront): the Jacobian phase keeps 2 lanes of a team busy and the
 // gate-matrix blocks 4, whatever the team size -- smaller teams waste fewer lanes there and take more rounds in the later phases
@@ -862,17 +864,32 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
         w2[0] = -dp[2] * g[1] + dp[1] * g[2]; w2[1] = dp[2] * g[0] - dp[0] * g[2]; w2[2] = -dp[1] * g[0] + dp[0] * g[1];
     }
     __syncthreads();
+    // F, and with it Phi = I + F dt + (F dt)^2 / 2 + (F dt)^3 / 6, is block sparse (five 3 x 3 blocks of F; the rows of Phi hold 1 .. 11 non-zeros
+    // of 21), and every product below reads both operands out of LDS -- at two LDS reads per multiply-add the dense products were
+    // bound by LDS bandwidth (1.2 G multiply-adds per 2,048-stream step, half of dk_begin's time).  The zero patterns are read off the
+    // matrices themselves (a bit mask per row / column) and the sums run over the non-zeros only, in the same ascending order: a
+    // skipped term is an exact zero, so the results are bit-identical to the dense sums.
+    __shared__ unsigned frow[IMU_DIM], fcol[IMU_DIM], prow[IMU_DIM];
     for (int i = tid; i < N * N; i += 256) F[i] *= a.dt;                       // Fdt
+    if (tid >= 128 && tid < 128 + N) {                                          // (scaling by dt keeps the pattern; a dt of 0 only zeroes more)
+        const int r = tid - 128; unsigned m = 0;
+        for (int k = 0; k < N; ++k) if (F[r * N + k] != 0.0) m |= 1u << k;
+        frow[r] = m;
+    } else if (tid >= 192 && tid < 192 + N) {
+        const int c = tid - 192; unsigned m = 0;
+        for (int k = 0; k < N; ++k) if (F[k * N + c] != 0.0) m |= 1u << k;
+        fcol[c] = m;
+    }
     __syncthreads();
     for (int i = tid; i < N * N; i += 256) {                                    // Fdt^2
         int r = i / N, c = i - r * N; double s = 0;
-        for (int k = 0; k < N; ++k) s += F[r * N + k] * F[k * N + c];
+        for (unsigned m = frow[r]; m; m &= m - 1) { const int k = __builtin_ctz(m); s += F[r * N + k] * F[k * N + c]; }
         F2[i] = s;
     }
     __syncthreads();
     for (int i = tid; i < N * N; i += 256) {                                    // Fdt^3, Phi
         int r = i / N, c = i - r * N; double s = 0;
-        for (int k = 0; k < N; ++k) s += F2[r * N + k] * F[k * N + c];
+        for (unsigned m = fcol[c]; m; m &= m - 1) { const int k = __builtin_ctz(m); s += F2[r * N + k] * F[k * N + c]; }
         Phi[i] = (r == c ? 1.0 : 0.0) + F[i] + F2[i] / 2. + s / 6.;
     }
     __syncthreads();
@@ -889,23 +906,30 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
         const double Au = p0 * u[0] + p1 * u[1] + p2 * u[2];
         const double d = Au - wv[r];
         Phi[row * N] = p0 - d * sv[0]; Phi[row * N + 1] = p1 - d * sv[1]; Phi[row * N + 2] = p2 - d * sv[2];
+    } else if (tid >= 128 && tid < 128 + N) {
+        // the pattern of the finished Phi: the entries the two patches rewrite at this moment (columns 0 .. 2 of rows 0 .. 2, 6 .. 8, 12 .. 14)
+        // count as non-zero whatever they hold
+        const int r = tid - 128; unsigned m = 0;
+        for (int k = 0; k < N; ++k) if (Phi[r * N + k] != 0.0) m |= 1u << k;
+        if (r < 3 || (r >= 6 && r < 9) || (r >= 12 && r < 15)) m |= 7u;
+        prow[r] = m;
     }
     __syncthreads();
     // three products with the finished Phi, side by side: T = Phi G (21 x 12, for Q = Phi G Qc G^T Phi^T dt), F2 = Phi P11, and in
     // batched mode Q <- Phi PhiT (the frame's accumulated transition; Q is only a buffer here, the noise term is added below)
     for (int i = tid; i < N * 12; i += 256) {
         int r = i / 12, c = i - r * 12; double s = 0;
-        for (int k = 0; k < N; ++k) s += Phi[r * N + k] * G[k * 12 + c];
+        for (unsigned m = prow[r]; m; m &= m - 1) { const int k = __builtin_ctz(m); s += Phi[r * N + k] * G[k * 12 + c]; }
         T[i] = s;
     }
     for (int i = tid; i < N * N; i += 256) {
         int r = i / N, c = i - r * N; double s = 0;
-        if (P11s) { for (int k = 0; k < N; ++k) s += Phi[r * N + k] * P11s[k * N + c]; }
-        else      { for (int k = 0; k < N; ++k) s += Phi[r * N + k] * a.P[(size_t)k * a.ld + c]; }
+        if (P11s) { for (unsigned m = prow[r]; m; m &= m - 1) { const int k = __builtin_ctz(m); s += Phi[r * N + k] * P11s[k * N + c]; } }
+        else      { for (unsigned m = prow[r]; m; m &= m - 1) { const int k = __builtin_ctz(m); s += Phi[r * N + k] * a.P[(size_t)k * a.ld + c]; } }
         F2[i] = s;                                                              // Phi P11
         if (P11s) {
             double s2 = 0;
-            for (int k = 0; k < N; ++k) s2 += Phi[r * N + k] * PhiT[k * N + c];
+            for (unsigned m = prow[r]; m; m &= m - 1) { const int k = __builtin_ctz(m); s2 += Phi[r * N + k] * PhiT[k * N + c]; }
             Q[i] = s2;
         }
     }
@@ -915,7 +939,7 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
         int r = i / N, c = i - r * N; double s = 0, q = 0;
         for (int k = 0; k < 12; ++k) q += T[r * 12 + k] * a.noise[k / 3] * T[c * 12 + k];
         q = q * a.dt;
-        for (int k = 0; k < N; ++k) s += F2[r * N + k] * Phi[c * N + k];
+        for (unsigned m = prow[c]; m; m &= m - 1) { const int k = __builtin_ctz(m); s += F2[r * N + k] * Phi[c * N + k]; }
         F[i] = s + q;
     }
     __syncthreads();
@@ -935,7 +959,7 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
         const int w = min(N, nc - c0);
         for (int i = tid; i < N * w; i += 256) {
             int r = i / w, c = i - r * w; double s = 0;
-            for (int k = 0; k < N; ++k) s += Phi[r * N + k] * a.P[(size_t)k * a.ld + N + c0 + c];
+            for (unsigned m = prow[r]; m; m &= m - 1) { const int k = __builtin_ctz(m); s += Phi[r * N + k] * a.P[(size_t)k * a.ld + N + c0 + c]; }
             T[i] = s;
         }
         __syncthreads();
@@ -1971,7 +1995,11 @@ __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict
 // per single-wavefront workgroup, blocked by 8 rows.  L (written by upd_chol_kernel) is the same for every lane: it is read
 // through the constant address space, i.e. by scalar loads into SGPRs that feed v_fma_f64 directly -- no LDS, no vector
 // load per L entry -- and the workgroups of one stream spread over three CUs instead of idling 114 threads of one.
-__global__ __launch_bounds__(64) void upd_fsolve_kernel(const UpdArgs* __restrict__ arr)
+// RB = rows per block step.  Every step re-reads the y of all earlier rows (a lane's own column, 512 coalesced bytes per row and
+// wavefront), so the kernel's memory traffic is k^2 / (2 RB) row reads per wavefront: with all streams of a batch resident at once
+// (6 k wavefronts, 0.3 GB of Y) those reads come from HBM, not from L2, and at RB = 8 they were what the kernel waited for.
+template <int RB>
+__device__ __forceinline__ void upd_fsolve_body(const UpdArgs* __restrict__ arr)
 {
     AV_FILTER_PRIO();
     const UpdArgsG a = upd_load(arr, blockIdx.y);
@@ -1987,33 +2015,35 @@ __global__ __launch_bounds__(64) void upd_fsolve_kernel(const UpdArgs* __restric
     const av_gptr<const double> src = (act && c < n) ? a.T + (size_t)c * ld : rcol;
     const av_gptr<double> y = (act && c < n) ? a.Kt + c : rcol;
     const size_t st_ = (act && c < n) ? (size_t)ld : 1;
-    for (int i0 = 0; i0 < k; i0 += 8) {
-        double acc[8];
+    for (int i0 = 0; i0 < k; i0 += RB) {
+        double acc[RB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] = (act && i0 + u < k) ? src[i0 + u] : 0.0;
-        int row[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) row[u] = min(i0 + u, k - 1) * ld;
-        // rows i0 .. i0+7 of column q: L^T(q, i0 + u) = Sbuf[q * ld + i0 + u] (i0 and ld are multiples of 8: one 64-byte line;
+        for (int u = 0; u < RB; ++u) acc[u] = (act && i0 + u < k) ? src[i0 + u] : 0.0;
+        // rows i0 .. i0+RB-1 of column q: L^T(q, i0 + u) = Sbuf[q * ld + i0 + u] (i0 and ld are multiples of 8: whole 64-byte lines;
         // the entries past row k - 1 of the last block multiply into accumulators that are never stored)
 #pragma unroll 4
         for (int q = 0; q < i0; ++q) {
             const double yq = act ? y[(size_t)q * st_] : 0.0;
             scalar_ptr Lq = L + q * ld + i0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] = __builtin_fma(-Lq[u], yq, acc[u]);
+            for (int u = 0; u < RB; ++u) acc[u] = __builtin_fma(-Lq[u], yq, acc[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < RB; ++u) {
             if (i0 + u < k) {
+                // L(i0 + u, i0 + w) = Sbuf[(i0 + u) * ld + i0 + w]
+                scalar_ptr Lu = L + (size_t)min(i0 + u, k - 1) * ld + i0;
 #pragma unroll
-                for (int w = 0; w < u; ++w) acc[u] = __builtin_fma(-L[row[u] + i0 + w], acc[w], acc[u]);
-                acc[u] /= L[row[u] + i0 + u];
+                for (int w = 0; w < u; ++w) acc[u] = __builtin_fma(-Lu[w], acc[w], acc[u]);
+                acc[u] /= Lu[u];
                 if (act) y[(size_t)(i0 + u) * st_] = acc[u];
             }
         }
     }
 }
+__global__ __launch_bounds__(64) void upd_fsolve_kernel(const UpdArgs* __restrict__ arr) { upd_fsolve_body<8>(arr); }
+__global__ __launch_bounds__(64) void upd_fsolve16_kernel(const UpdArgs* __restrict__ arr) { upd_fsolve_body<16>(arr); }
+__global__ __launch_bounds__(64) void upd_fsolve32_kernel(const UpdArgs* __restrict__ arr) { upd_fsolve_body<32>(arr); }
 
 // P <- sym(P - Y^T Y) in place (msckf.py:597-602): the 4 x 4 sub-tiles on and below the diagonal are formed, each owner
 // reads its sub-tile of P and the mirror sub-tile, then writes both -- every unordered pair {(r,c), (c,r)} has one owner.
