@@ -365,7 +365,9 @@ class CompletePath(object):
         two steps behind (vio.py:46-51 with the feature queue on the device)."""
         from uav_airvision_amd import _native as N
         torch = self.torch
-        serial = os.environ.get('AV_BENCH_SERIAL')           # diagnostic: front-end and filter strictly alternate (exclusive GPU times add up)
+        # serial: front-end and filter strictly alternate (exclusive GPU times add up) -- the warm-up steps of the default run (the filter's
+        # chain timed with the GPU to itself: roofline_msckf.exclusive), or the whole run as a diagnostic (AV_BENCH_SERIAL=1)
+        serial = os.environ.get('AV_BENCH_SERIAL') or getattr(self, 'force_serial', False)
         for k in range(k_begin, k_end):
             self.run_fe(k)
             if serial:
@@ -589,8 +591,15 @@ def main():
         sys.stderr.write('bench.py: pre-roll did not reach the steady state: %s\n' % c_pre)
         return 3
     # ---- the contract's W untimed warm-up steps ----
+    # (device-resident filter: stepped with front-end and filter strictly alternating, the filter's phase chains under HIP events --
+    #  what the chain takes with the GPU to itself, reported beside the in-path figure as roofline_msckf.exclusive)
+    w_e0 = None
     if flt is not None and Wm > 0:
+        if flt.device_resident():
+            w_e0 = flt.work(enable=1)
+            path.force_serial = True
         run_pipelined(PRE, PRE + Wm)
+        path.force_serial = False
     else:
         for k in range(PRE, PRE + Wm):
             run(k)
@@ -736,13 +745,20 @@ def main():
             tf = fl / (dw['chain_ms'] * 1e-3) / 1e12 if dw['chain_ms'] > 0 else 0.0
             out['roofline_msckf'] = {
                 'bound': 'fp64 vector FMA (= fp64 MFMA peak on MI355X); the stage itself is latency / LDS bound (SURVEY 8d)',
-                'kernels': 'triangulate, feature_kernel<16|64|256>, upd_stack, upd_info, update_front_batch, upd_gather/tt/s/chol/fsolve/p',
+                'kernels': 'triangulate, feature_kernel<256> / feature_kernel8, upd_stack, upd_rowmap/gram/gram_chol, upd_gather/tt/s/chol/fsolve/p, upd_info (device-resident filter: the spans also hold dk_mid)',
                 'achieved': tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / FP64_PEAK_TFLOPS,
                 'algorithmic_flops_per_step': fl / K, 'gate_flops_per_step': dw['gate_flops'] / K, 'update_flops_per_step': dw['update_flops'] / K,
                 'reference_qr_flops_per_step_not_counted': dw['reference_qr_flops'] / K,
                 'features_gated_per_stream_step': dw['features_gated'] / K / S, 'rows_stacked_per_update': dw['rows_stacked'] / max(dw['updates'], 1.0),
                 'updates_per_stream_step': dw['updates'] / K / S,
                 'chain_ms_per_step': dw['chain_ms'] / K,
+                'exclusive': None if w_e0 is None or w_t0['chain_ms'] <= w_e0['chain_ms'] else {
+                    'chain_ms_per_step': (w_t0['chain_ms'] - w_e0['chain_ms']) / Wm,
+                    'achieved': ((w_t0['gate_flops'] - w_e0['gate_flops']) + (w_t0['update_flops'] - w_e0['update_flops'])) / ((w_t0['chain_ms'] - w_e0['chain_ms']) * 1e-3) / 1e12,
+                    'frac': ((w_t0['gate_flops'] - w_e0['gate_flops']) + (w_t0['update_flops'] - w_e0['update_flops'])) / ((w_t0['chain_ms'] - w_e0['chain_ms']) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                    'steps': Wm,
+                    'how': 'the same counters and events over the %d warm-up steps, which this bench runs with front-end and filter strictly alternating '
+                           '(a device synchronisation between them): the filter\'s chains with the GPU to themselves' % Wm},
                 'how': 'flops: SURVEY 8(d) formulas on the sizes actually processed (gate: r = 4M-3 rows x n; update: k = min(m, n) rows kept), '
                        'the reference-size thin QR (2mn^2 - 2/3 n^3, msckf.py:554) listed apart because the column-compressed update never runs it; '
                        'time: HIP events on every stream group\'s stream around the launches of each phase (triangulation .. covariance update), '
