@@ -102,6 +102,17 @@ int av_undistort_points(const double* pts_dev, int n, const double* intr, const 
 int av_distort_points(const double* pts_dev, int n, const double* intr, const double* dist,
                       double* out_dev, void* stream);
 
+/* The same two operators with the distortion model as an argument (camera_model.py:41-46, 69-74; feature_publisher.py:53-58,
+ * 82-87): AV_DISTORTION_RADTAN = the two above; AV_DISTORTION_EQUIDISTANT = cv2.fisheye.undistortPoints(pts, K, D, R, P = identity)
+ * and cv2.fisheye.distortPoints(pts, K, D), dist = [k1 k2 k3 k4] of the Kannala-Brandt model.  (Parity of the equidistant branch
+ * is unpinned: restated from OpenCV 4.x fisheye.cpp, no cv2 to check against) */
+#define AV_DISTORTION_RADTAN 0
+#define AV_DISTORTION_EQUIDISTANT 1
+int av_undistort_points_model(const double* pts_dev, int n, const double* intr, const double* dist, const double* R, int model,
+                              double* out_dev, void* stream);
+int av_distort_points_model(const double* pts_dev, int n, const double* intr, const double* dist, int model,
+                            double* out_dev, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * The image front-end as one device-resident engine over n_streams independent stereo streams:
  * ImageProcessingPipeline.__init__ / imu_callback / stereo_callback
@@ -130,6 +141,8 @@ typedef struct av_frontend_config {
     double  R0to1[9];                        /* R_cam1_imu.T @ R_cam0_imu (stereo_matcher.py:47)    */
     double  E[9];                            /* skew(t01) @ R0to1 (stereo_matcher.py:90-91)         */
     double  norm_unit;                       /* 4/(2fx+2fy) of cam0 (stereo_matcher.py:103-104)     */
+    int32_t cam0_distortion_model;           /* AV_DISTORTION_* (config.py:98); 0 = radtan          */
+    int32_t cam1_distortion_model;           /* config.py:117                                       */
 } av_frontend_config;
 
 typedef struct av_frontend av_frontend;

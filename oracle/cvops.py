@@ -127,10 +127,11 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def undistort_points(pts_in, intrinsics, distortion_coeffs, rectification_matrix=None):
+def undistort_points(pts_in, intrinsics, distortion_coeffs, rectification_matrix=None, distortion_model='radtan'):
     """cv2.undistortPoints(pts, K, D, None, R, P=identity) as wrapped by camera_model.py:24-47 and
-    feature_publisher.py:24-59 (new_intrinsics = [1,1,0,0]).  Output dtype follows the input
-    array dtype the way OpenCV does: float32 in -> float32 out, anything else -> float64."""
+    feature_publisher.py:24-59 (new_intrinsics = [1,1,0,0]); distortion_model 'equidistant' =
+    cv2.fisheye.undistortPoints(pts, K, D, R, P=identity) (camera_model.py:41-43; parity unpinned, see imgops.c).  Output dtype
+    follows the input array dtype the way OpenCV does: float32 in -> float32 out, anything else -> float64."""
     arr = np.asarray(pts_in)
     out_f32 = arr.dtype == np.float32
     pts = np.ascontiguousarray(arr.reshape(-1, 2), dtype=np.float64)
@@ -138,19 +139,22 @@ def undistort_points(pts_in, intrinsics, distortion_coeffs, rectification_matrix
     kd = np.ascontiguousarray(intrinsics, dtype=np.float64)
     dd = np.ascontiguousarray(distortion_coeffs, dtype=np.float64)
     out = np.empty_like(pts)
-    lib().orc_undistort_points(_dp(pts), C.c_int(pts.shape[0]), _dp(kd), _dp(dd), _dp(R), _dp(out))
+    fn = lib().orc_undistort_points_fisheye if distortion_model == 'equidistant' else lib().orc_undistort_points
+    fn(_dp(pts), C.c_int(pts.shape[0]), _dp(kd), _dp(dd), _dp(R), _dp(out))
     return out.astype(np.float32) if out_f32 else out
 
 
-def distort_points(pts_in, intrinsics, distortion_coeffs):
-    """cv2.projectPoints(convertPointsToHomogeneous(pts), 0, 0, K, D) (camera_model.py:49-75)."""
+def distort_points(pts_in, intrinsics, distortion_coeffs, distortion_model='radtan'):
+    """cv2.projectPoints(convertPointsToHomogeneous(pts), 0, 0, K, D) (camera_model.py:49-75); distortion_model
+    'equidistant' = cv2.fisheye.distortPoints(pts, K, D) (camera_model.py:69-70; parity unpinned, see imgops.c)."""
     arr = np.asarray(pts_in)
     out_f32 = arr.dtype == np.float32
     pts = np.ascontiguousarray(arr.reshape(-1, 2), dtype=np.float64)
     kd = np.ascontiguousarray(intrinsics, dtype=np.float64)
     dd = np.ascontiguousarray(distortion_coeffs, dtype=np.float64)
     out = np.empty_like(pts)
-    lib().orc_distort_points(_dp(pts), C.c_int(pts.shape[0]), _dp(kd), _dp(dd), _dp(out))
+    fn = lib().orc_distort_points_fisheye if distortion_model == 'equidistant' else lib().orc_distort_points
+    fn(_dp(pts), C.c_int(pts.shape[0]), _dp(kd), _dp(dd), _dp(out))
     return out.astype(np.float32) if out_f32 else out
 
 

@@ -101,8 +101,9 @@ def stereo_match(img0, img1, cam0_points, config, geom, cache_pyramids=False):
         return np.array([]), np.array([], dtype=bool), {}
     K0, D0 = config.cam0_intrinsics, config.cam0_distortion_coeffs
     pts0 = np.array(cam0_points, dtype=np.float32)
-    und0 = cvops.undistort_points(pts0, K0, D0, geom.R0to1)
-    proj1 = cvops.distort_points(und0, K0, D0)
+    M0 = getattr(config, 'cam0_distortion_model', 'radtan')
+    und0 = cvops.undistort_points(pts0, K0, D0, geom.R0to1, distortion_model=M0)
+    proj1 = cvops.distort_points(und0, K0, D0, distortion_model=M0)
     lk = dict(config.lk_params)
     p1, track_mask, _ = cvops.calc_optical_flow_pyr_lk(img0, img1, pts0, np.array(proj1, dtype=np.float32),
                                                        cache_pyramids=cache_pyramids, **lk)
@@ -117,8 +118,8 @@ def stereo_match(img0, img1, cam0_points, config, geom, cache_pyramids=False):
             x, y = p1[i]
             if x < 0 or x >= w or y < 0 or y >= h:
                 inlier[i] = False
-    undist0 = cvops.undistort_points(pts0, K0, D0)
-    undist1 = cvops.undistort_points(p1, K0, D0)
+    undist0 = cvops.undistort_points(pts0, K0, D0, distortion_model=M0)
+    undist1 = cvops.undistort_points(p1, K0, D0, distortion_model=M0)
     thr = config.stereo_threshold * geom.norm_unit
     E = geom.E
     for i in range(len(p1)):
@@ -309,8 +310,10 @@ class OracleFrontend(object):
         p0 = [f.cam0_point for f in feats]
         p1 = [f.cam1_point for f in feats]
         if feats:
-            u0 = cvops.undistort_points(np.reshape(p0, (-1, 1, 2)), cfg.cam0_intrinsics, cfg.cam0_distortion_coeffs)
-            u1 = cvops.undistort_points(np.reshape(p1, (-1, 1, 2)), cfg.cam1_intrinsics, cfg.cam1_distortion_coeffs)
+            u0 = cvops.undistort_points(np.reshape(p0, (-1, 1, 2)), cfg.cam0_intrinsics, cfg.cam0_distortion_coeffs,
+                                        distortion_model=getattr(cfg, 'cam0_distortion_model', 'radtan'))
+            u1 = cvops.undistort_points(np.reshape(p1, (-1, 1, 2)), cfg.cam1_intrinsics, cfg.cam1_distortion_coeffs,
+                                        distortion_model=getattr(cfg, 'cam1_distortion_model', 'radtan'))
         out = []
         for i in range(len(ids)):
             m = Meas()

@@ -393,3 +393,69 @@ ORC_API void orc_distort_points(const double* pts, int n, const double* kd, cons
         out[2 * i + 1] = yd * fy + cy;
     }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * The 'equidistant' (fisheye, Kannala-Brandt) model of camera_model.py:41-42, 69-70 / feature_publisher.py:53-54, 82-83:
+ * cv2.fisheye.undistortPoints(pts, K, D, R, P = identity) and cv2.fisheye.distortPoints(pts, K, D).
+ * PARITY UNPINNED: cv2 cannot be installed here and the reference's tests hold no vector for this model (EuRoC is radtan,
+ * config.py:98,117); restated from OpenCV 4.x modules/calib3d/src/fisheye.cpp (cv::fisheye::undistortPoints with its default
+ * TermCriteria(MAX_ITER + EPS, 10, 1e-8), cv::fisheye::distortPoints with alpha = 0), expression order kept.
+ * ------------------------------------------------------------------------------------------------------------------------- */
+ORC_API void orc_undistort_points_fisheye(const double* pts, int n, const double* kd, const double* dist, const double* R, double* out)
+{
+    const double fx = kd[0], fy = kd[1], cx = kd[2], cy = kd[3];
+    const double k0 = dist[0], k1 = dist[1], k2 = dist[2], k3 = dist[3];
+    const double eps = 1e-8, half_pi = 3.1415926535897932384626433832795 / 2.;
+    for (int i = 0; i < n; ++i) {
+        const double pwx = (pts[2 * i] - cx) / fx, pwy = (pts[2 * i + 1] - cy) / fy;
+        double theta_d = sqrt(pwx * pwx + pwy * pwy);
+        /* the model is only valid up to 180 degrees of field of view: clip */
+        theta_d = fmin(fmax(-half_pi, theta_d), half_pi);
+        int converged = 0;
+        double theta = theta_d, scale = 0.0;
+        if (fabs(theta_d) > eps) {
+            for (int j = 0; j < 10; ++j) {               /* Newton's method on theta (1 + k0 theta^2 + ...) = theta_d */
+                const double theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta6 * theta2;
+                const double k0_theta2 = k0 * theta2, k1_theta4 = k1 * theta4, k2_theta6 = k2 * theta6, k3_theta8 = k3 * theta8;
+                const double theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                                         (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+                theta = theta - theta_fix;
+                if (fabs(theta_fix) < eps) { converged = 1; break; }
+            }
+            scale = tan(theta) / theta_d;
+        } else {
+            converged = 1;
+        }
+        /* theta must keep its sign: a flip means convergence on the other side of the camera centre */
+        const int flipped = (theta_d < 0 && theta > 0) || (theta_d > 0 && theta < 0);
+        if (converged && !flipped) {
+            const double pux = pwx * scale, puy = pwy * scale;
+            const double xx = R[0] * pux + R[1] * puy + R[2];
+            const double yy = R[3] * pux + R[4] * puy + R[5];
+            const double ww = R[6] * pux + R[7] * puy + R[8];
+            out[2 * i] = xx / ww;
+            out[2 * i + 1] = yy / ww;
+        } else {
+            out[2 * i] = -1000000.0;
+            out[2 * i + 1] = -1000000.0;
+        }
+    }
+}
+
+ORC_API void orc_distort_points_fisheye(const double* pts, int n, const double* kd, const double* dist, double* out)
+{
+    const double fx = kd[0], fy = kd[1], cx = kd[2], cy = kd[3];
+    const double k0 = dist[0], k1 = dist[1], k2 = dist[2], k3 = dist[3];
+    for (int i = 0; i < n; ++i) {
+        const double x = pts[2 * i], y = pts[2 * i + 1];
+        const double r2 = x * x + y * y, r = sqrt(r2);
+        const double theta = atan(r);
+        const double theta2 = theta * theta, theta3 = theta2 * theta, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
+        const double theta_d = theta + k0 * theta3 + k1 * theta5 + k2 * theta7 + k3 * theta9;
+        const double inv_r = r > 1e-8 ? 1.0 / r : 1;
+        const double cdist = r > 1e-8 ? theta_d * inv_r : 1;
+        const double xd = x * cdist, yd = y * cdist;
+        out[2 * i] = xd * fx + cx;                       /* alpha (skew) = 0 */
+        out[2 * i + 1] = yd * fy + cy;
+    }
+}

@@ -150,6 +150,41 @@ def test_fast_capacity_error(ops, frames0, cfg):
         ops.fast_detect(frames0[0].cam0_image, cfg.fast_threshold, cap=64)
 
 
+def test_equidistant_undistort_distort_match_the_oracle(ops, cfg):
+    """camera_model.py:41-43, 69-70 with distortion_model 'equidistant' (cv2.fisheye.*): same restatement on both sides; the only
+    difference is tan / atan from the device math library against libm, so the comparison allows a few ulp of fp64 and float32
+    results must agree to the last bit almost everywhere."""
+    from oracle import cvops
+    K = np.array([461.6, 460.3, 362.7, 248.1]); D = np.array([-0.0126, 0.0129, -0.0161, 0.0062])
+    rng = np.random.default_rng(3)
+    pts = np.stack([rng.uniform(-30, 780, 4000), rng.uniform(-30, 510, 4000)], 1)
+    pts[0] = (K[2], K[3])                                           # the principal point: theta_d below epsilon
+    R = cvops.rodrigues(np.array([0.01, -0.02, 0.005]))
+    for dtype in (np.float32, np.float64):
+        p = pts.astype(dtype)
+        a = ops.undistort_points(p, K, D, R, distortion_model='equidistant')
+        b = cvops.undistort_points(p, K, D, R, distortion_model='equidistant')
+        assert a.dtype == b.dtype == dtype
+        if dtype == np.float64:
+            assert np.abs(a - b).max() <= 4e-16 * max(1.0, np.abs(b).max())
+        else:
+            assert (a != b).mean() < 1e-3 and np.abs(a - b).max() < 1e-6
+        a2 = ops.distort_points(b, K, D, distortion_model='equidistant')
+        b2 = cvops.distort_points(b, K, D, distortion_model='equidistant')
+        if dtype == np.float64:
+            assert np.abs(a2 - b2).max() <= 1e-12
+        else:
+            assert (a2 != b2).mean() < 1e-3 and np.abs(a2 - b2).max() < 1e-3
+    # the radtan entry points and the model argument agree
+    assert np.array_equal(ops.undistort_points(pts, cfg.cam0_intrinsics, cfg.cam0_distortion_coeffs, R, distortion_model='radtan'),
+                          cvops.undistort_points(pts, cfg.cam0_intrinsics, cfg.cam0_distortion_coeffs, R))
+    from uav_airvision_amd import _native as N
+    import torch
+    d = torch.zeros(4, dtype=torch.float64, device='cuda')
+    with pytest.raises(N.AirvisionError, match='distortion model'):
+        N.check(N.lib().av_undistort_points_model(N.dptr(d), 2, N.darr(K), N.darr(D), None, 7, N.dptr(d), None))
+
+
 def test_undistort_distort_bit_exact(ops, cfg):
     from oracle import cvops
     rng = np.random.default_rng(2)

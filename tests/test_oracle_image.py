@@ -176,3 +176,48 @@ def test_rodrigues_matches_scipy():
         v = rng.normal(0, 0.5, 3)
         assert np.allclose(cvops.rodrigues(v), Rotation.from_rotvec(v).as_matrix(), atol=1e-14)
     assert np.array_equal(cvops.rodrigues(np.zeros(3)), np.eye(3))
+
+
+
+def test_equidistant_model_against_an_independent_solution():
+    """The 'equidistant' branch of camera_model.py:41-43, 69-70 (cv2.fisheye.undistortPoints / distortPoints).  cv2 is not
+    installable here and the reference holds no vector for this model, so the C restatement (oracle/imgops.c, from OpenCV 4.x
+    fisheye.cpp) is checked against the model's definition solved another way: theta_d = theta (1 + k1 theta^2 + ... + k4
+    theta^8), r_d = theta_d, r_u = tan(theta) -- forward by the formula in numpy, inverse by bisection on the monotone
+    polynomial -- plus the round trip, the principal point, the rotation and the dtype rule."""
+    from oracle import cvops
+    K = np.array([461.6, 460.3, 362.7, 248.1])
+    D = np.array([-0.0126, 0.0129, -0.0161, 0.0062])            # a typical Kannala-Brandt calibration of a wide-angle lens
+    rng = np.random.default_rng(5)
+    px = np.stack([rng.uniform(5, 747, 3000), rng.uniform(5, 475, 3000)], 1)
+    und = cvops.undistort_points(px, K, D, distortion_model='equidistant')
+    assert und.dtype == np.float64 and und.shape == px.shape
+    # independent inverse: bisection for theta in [0, pi/2)
+    xd = (px[:, 0] - K[2]) / K[0]; yd = (px[:, 1] - K[3]) / K[1]
+    rd = np.hypot(xd, yd)
+    poly = lambda t: t * (1 + D[0] * t**2 + D[1] * t**4 + D[2] * t**6 + D[3] * t**8)
+    lo, hi = np.zeros_like(rd), np.full_like(rd, 1.5)
+    for _ in range(80):
+        mid = 0.5 * (lo + hi); big = poly(mid) > rd
+        hi = np.where(big, mid, hi); lo = np.where(big, lo, mid)
+    theta = 0.5 * (lo + hi)
+    scale = np.tan(theta) / rd
+    assert np.abs(und - np.stack([xd * scale, yd * scale], 1)).max() < 1e-9
+    # forward model by the formula, and the round trip through both C functions
+    r = np.hypot(und[:, 0], und[:, 1]); th = np.arctan(r)
+    ref = np.stack([und[:, 0] * poly(th) / r * K[0] + K[2], und[:, 1] * poly(th) / r * K[1] + K[3]], 1)
+    back = cvops.distort_points(und, K, D, distortion_model='equidistant')
+    assert np.abs(back - ref).max() < 1e-9 and np.abs(back - px).max() < 1e-6
+    # the principal point maps to the optical axis (theta_d below the criteria's epsilon: scale 0), and back to itself
+    c = cvops.undistort_points(np.array([[K[2], K[3]]]), K, D, distortion_model='equidistant')
+    assert np.array_equal(c, np.zeros((1, 2)))
+    assert np.allclose(cvops.distort_points(np.zeros((1, 2)), K, D, distortion_model='equidistant'), [[K[2], K[3]]], atol=0, rtol=0)
+    # rectification matrix applied to (x, y, 1), then the perspective division -- as in the radtan wrapper
+    R = cvops.rodrigues(np.array([0.02, -0.01, 0.03]))
+    ur = cvops.undistort_points(px[:50], K, D, R, distortion_model='equidistant')
+    h = (R @ np.concatenate([und[:50], np.ones((50, 1))], 1).T).T
+    assert np.abs(ur - h[:, :2] / h[:, 2:]).max() < 1e-12
+    # float32 in -> float32 out (OpenCV's depth rule, which the feature publisher relies on)
+    assert cvops.undistort_points(px.astype(np.float32), K, D, distortion_model='equidistant').dtype == np.float32
+    # and the two models really differ
+    assert np.abs(und - cvops.undistort_points(px, K, D)).max() > 1e-3

@@ -18,6 +18,14 @@ AV_OK, AV_E_INVALID, AV_E_HIP, AV_E_CAPACITY, AV_E_NODEVICE, AV_E_NUMERIC = 0, -
 AV_FE_INPUTS_PERSIST = 1
 
 
+DISTORTION_MODELS = {'radtan': 0, 'equidistant': 1}          # AV_DISTORTION_* (include/airvision.h)
+
+
+def distortion_model_code(name):
+    """'radtan' / 'equidistant' (config.py:98,117; camera_model.py:41,69: anything but 'equidistant' is radtan there) -> AV_DISTORTION_*."""
+    return 1 if name == 'equidistant' else 0
+
+
 class AirvisionError(RuntimeError):
     def __init__(self, code, text):
         RuntimeError.__init__(self, 'libairvision_hip error %d: %s' % (code, text))
@@ -42,7 +50,8 @@ class FrontendConfig(C.Structure):
                 ('cam0_intrinsics', C.c_double * 4), ('cam0_distortion', C.c_double * 4),
                 ('cam1_intrinsics', C.c_double * 4), ('cam1_distortion', C.c_double * 4),
                 ('R_cam0_imu', C.c_double * 9), ('R_cam1_imu', C.c_double * 9),
-                ('R0to1', C.c_double * 9), ('E', C.c_double * 9), ('norm_unit', C.c_double)]
+                ('R0to1', C.c_double * 9), ('E', C.c_double * 9), ('norm_unit', C.c_double),
+                ('cam0_distortion_model', C.c_int32), ('cam1_distortion_model', C.c_int32)]
 
 
 # name -> (restype, argtypes); the list doubles as the export check of tests/test_abi.py
@@ -58,6 +67,8 @@ SIGNATURES = {
     'av_fast_detect': (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P]),
     'av_undistort_points': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _P, _P]),
     'av_distort_points': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _P, _P]),
+    'av_undistort_points_model': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, _P, _P]),
+    'av_distort_points_model': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, _P, _P]),
     'av_frontend_create': (C.c_int, [C.POINTER(FrontendConfig), C.c_int, C.c_int, C.POINTER(_P)]),
     'av_frontend_destroy': (None, [_P]),
     'av_frontend_push_imu': (C.c_int, [_P, C.c_int, C.c_double, C.POINTER(C.c_double)]),

@@ -38,7 +38,8 @@ PyrGeom av_make_geom(const av_pyr_layout& l);
 
 // ---- camera model, by value -------------------------------------------------------------------
 struct CamModel {
-    double fx, fy, cx, cy, k1, k2, p1, p2;
+    double fx, fy, cx, cy, k1, k2, p1, p2;       // equidistant: k1, k2, p1, p2 hold the model's k1 .. k4
+    int model;                                    // AV_DISTORTION_RADTAN (0) / AV_DISTORTION_EQUIDISTANT (1)
 };
 
 // packed FAST keypoint word: score << 19 | (2^19-1 - raster)
@@ -56,8 +57,58 @@ __device__ __forceinline__ int av_reflect101(int p, int len)
 
 // cv2.undistortPoints core: 5 fixed-point iterations of the radtan inverse, then R*[x y 1].
 // Expression order follows OpenCV's cvUndistortPointsInternal; fp64, no contraction.
+// cv2.fisheye.undistortPoints core (camera_model.py:41-43): Newton's method on theta (1 + k1 theta^2 + ...) = theta_d, at most 10 steps,
+// eps 1e-8 (OpenCV 4.x fisheye.cpp, default TermCriteria), then scale = tan(theta) / theta_d and R * [x y 1].  Parity unpinned
+// (the CPU checker holds the same restatement; tan from the device math library vs libm: a few ulp).
+__device__ __forceinline__ void av_undistort_fisheye(const CamModel& c, const double* R, double u, double v, double& ox, double& oy)
+{
+    const double pwx = (u - c.cx) / c.fx, pwy = (v - c.cy) / c.fy;
+    const double half_pi = 3.1415926535897932384626433832795 / 2.;
+    double theta_d = sqrt(pwx * pwx + pwy * pwy);
+    theta_d = fmin(fmax(-half_pi, theta_d), half_pi);
+    bool converged = false;
+    double theta = theta_d, scale = 0.0;
+    if (fabs(theta_d) > 1e-8) {
+#pragma unroll 1
+        for (int j = 0; j < 10; ++j) {
+            const double theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta6 * theta2;
+            const double k0_theta2 = c.k1 * theta2, k1_theta4 = c.k2 * theta4, k2_theta6 = c.p1 * theta6, k3_theta8 = c.p2 * theta8;
+            const double theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                                     (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+            theta = theta - theta_fix;
+            if (fabs(theta_fix) < 1e-8) { converged = true; break; }
+        }
+        scale = tan(theta) / theta_d;
+    } else {
+        converged = true;
+    }
+    const bool flipped = (theta_d < 0 && theta > 0) || (theta_d > 0 && theta < 0);
+    if (converged && !flipped) {
+        const double pux = pwx * scale, puy = pwy * scale;
+        const double xx = R[0] * pux + R[1] * puy + R[2];
+        const double yy = R[3] * pux + R[4] * puy + R[5];
+        const double ww = R[6] * pux + R[7] * puy + R[8];
+        ox = xx / ww; oy = yy / ww;
+    } else {
+        ox = -1000000.0; oy = -1000000.0;
+    }
+}
+// cv2.fisheye.distortPoints (camera_model.py:69-70), alpha = 0
+__device__ __forceinline__ void av_distort_fisheye(const CamModel& c, double x, double y, double& ou, double& ov)
+{
+    const double r2 = x * x + y * y, r = sqrt(r2);
+    const double theta = atan(r);
+    const double theta2 = theta * theta, theta3 = theta2 * theta, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
+    const double theta_d = theta + c.k1 * theta3 + c.k2 * theta5 + c.p1 * theta7 + c.p2 * theta9;
+    const double inv_r = r > 1e-8 ? 1.0 / r : 1;
+    const double cdist = r > 1e-8 ? theta_d * inv_r : 1;
+    ou = x * cdist * c.fx + c.cx;
+    ov = y * cdist * c.fy + c.cy;
+}
+
 __device__ __forceinline__ void av_undistort(const CamModel& c, const double* R, double u, double v, double& ox, double& oy)
 {
+    if (c.model == 1) { av_undistort_fisheye(c, R, u, v, ox, oy); return; }
     const double ifx = 1. / c.fx, ify = 1. / c.fy;
     double x = (u - c.cx) * ifx, y = (v - c.cy) * ify;
     const double x0 = x, y0 = y;
@@ -81,6 +132,7 @@ __device__ __forceinline__ void av_undistort(const CamModel& c, const double* R,
 // cv2.projectPoints with zero rvec/tvec on (x, y, 1): radtan forward + K.
 __device__ __forceinline__ void av_distort(const CamModel& c, double x, double y, double& ou, double& ov)
 {
+    if (c.model == 1) { av_distort_fisheye(c, x, y, ou, ov); return; }
     double r2 = x * x + y * y, r4 = r2 * r2;
     double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
     double cdist = 1 + c.k1 * r2 + c.k2 * r4;

@@ -837,9 +837,9 @@ AV_EXPORT int av_frontend_create(const av_frontend_config* cfg, int n_streams, i
     d.NSORT = ns;
     if (ns > 4096) { av_set_error("av_frontend_create: grid_num*(grid_max+grid_min) = %d exceeds 4096", C * (d.gmax + d.gmin)); delete fe; return AV_E_INVALID; }
     d.cam0 = CamModel{cfg->cam0_intrinsics[0], cfg->cam0_intrinsics[1], cfg->cam0_intrinsics[2], cfg->cam0_intrinsics[3],
-                      cfg->cam0_distortion[0], cfg->cam0_distortion[1], cfg->cam0_distortion[2], cfg->cam0_distortion[3]};
+                      cfg->cam0_distortion[0], cfg->cam0_distortion[1], cfg->cam0_distortion[2], cfg->cam0_distortion[3], cfg->cam0_distortion_model};
     d.cam1 = CamModel{cfg->cam1_intrinsics[0], cfg->cam1_intrinsics[1], cfg->cam1_intrinsics[2], cfg->cam1_intrinsics[3],
-                      cfg->cam1_distortion[0], cfg->cam1_distortion[1], cfg->cam1_distortion[2], cfg->cam1_distortion[3]};
+                      cfg->cam1_distortion[0], cfg->cam1_distortion[1], cfg->cam1_distortion[2], cfg->cam1_distortion[3], cfg->cam1_distortion_model};
     for (int i = 0; i < 9; ++i) { d.R0to1[i] = cfg->R0to1[i]; d.E[i] = cfg->E[i]; d.I3[i] = (i % 4 == 0) ? 1.0 : 0.0; }
     d.epi_thr = cfg->stereo_threshold * cfg->norm_unit;
 

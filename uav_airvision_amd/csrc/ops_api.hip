@@ -67,3 +67,28 @@ AV_EXPORT int av_distort_points(const double* pts_dev, int n, const double* intr
     AV_LAUNCH_CHECK();
     return AV_OK;
 }
+
+// the same two operators with the distortion model of camera_model.py:41, 69 as an argument
+AV_EXPORT int av_undistort_points_model(const double* pts_dev, int n, const double* intr, const double* dist, const double* R, int model,
+                                        double* out_dev, void* stream)
+{
+    if (!pts_dev || !out_dev || !intr || !dist || n < 0) { av_set_error("av_undistort_points_model: bad arguments"); return AV_E_INVALID; }
+    if (model != AV_DISTORTION_RADTAN && model != AV_DISTORTION_EQUIDISTANT) { av_set_error("av_undistort_points_model: unknown distortion model %d", model); return AV_E_INVALID; }
+    if (n == 0) return AV_OK;
+    CamModel c{intr[0], intr[1], intr[2], intr[3], dist[0], dist[1], dist[2], dist[3], model};
+    RMat r;
+    for (int i = 0; i < 9; ++i) r.m[i] = R ? R[i] : ((i % 4 == 0) ? 1.0 : 0.0);
+    hipLaunchKernelGGL(undistort_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pts_dev, n, c, r, out_dev);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}
+AV_EXPORT int av_distort_points_model(const double* pts_dev, int n, const double* intr, const double* dist, int model, double* out_dev, void* stream)
+{
+    if (!pts_dev || !out_dev || !intr || !dist || n < 0) { av_set_error("av_distort_points_model: bad arguments"); return AV_E_INVALID; }
+    if (model != AV_DISTORTION_RADTAN && model != AV_DISTORTION_EQUIDISTANT) { av_set_error("av_distort_points_model: unknown distortion model %d", model); return AV_E_INVALID; }
+    if (n == 0) return AV_OK;
+    CamModel c{intr[0], intr[1], intr[2], intr[3], dist[0], dist[1], dist[2], dist[3], model};
+    hipLaunchKernelGGL(distort_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pts_dev, n, c, out_dev);
+    AV_LAUNCH_CHECK();
+    return AV_OK;
+}

@@ -15,8 +15,6 @@ class CameraModel(object):
 
     @staticmethod
     def _check(distortion_model, new_intrinsics=None):
-        if distortion_model == 'equidistant':
-            raise NotImplementedError('only the radtan model is built (EuRoC, config.py:98,117)')
         if new_intrinsics is not None and list(new_intrinsics) != [1, 1, 0, 0]:
             raise NotImplementedError('new_intrinsics other than [1,1,0,0] are not used by the reference')
 
@@ -26,14 +24,15 @@ class CameraModel(object):
         if len(pts_in) == 0:
             return []
         self._check(distortion_model, new_intrinsics)
-        return ops.undistort_points(np.reshape(pts_in, (-1, 1, 2)), intrinsics, distortion_coeffs, rectification_matrix)
+        return ops.undistort_points(np.reshape(pts_in, (-1, 1, 2)), intrinsics, distortion_coeffs, rectification_matrix,
+                                    distortion_model=distortion_model)       # 'equidistant' -> cv2.fisheye.undistortPoints, else radtan (:41-46)
 
     def distort_points(self, pts_in, intrinsics, distortion_model, distortion_coeffs):
         """camera_model.py:49-75."""
         if len(pts_in) == 0:
             return []
         self._check(distortion_model)
-        return ops.distort_points(pts_in, intrinsics, distortion_coeffs)
+        return ops.distort_points(pts_in, intrinsics, distortion_coeffs, distortion_model=distortion_model)
 
     def predict_feature_tracking(self, input_pts, R_p_c, intrinsics):
         """camera_model.py:77-93 (unused by the pipeline; kept for API compatibility)."""

@@ -40,8 +40,8 @@ def pack_frontend_config(config, max_corners=8192):
     for name, src in (('cam0_intrinsics', config.cam0_intrinsics), ('cam0_distortion', config.cam0_distortion_coeffs),
                       ('cam1_intrinsics', config.cam1_intrinsics), ('cam1_distortion', config.cam1_distortion_coeffs)):
         getattr(c, name)[:] = [float(v) for v in src]
-    if config.cam0_distortion_model != 'radtan' or config.cam1_distortion_model != 'radtan':
-        raise ValueError('only the radtan distortion model is implemented (EuRoC, config.py:98,117)')
+    c.cam0_distortion_model = N.distortion_model_code(config.cam0_distortion_model)      # 'equidistant' = cv2.fisheye.* (camera_model.py:41,69)
+    c.cam1_distortion_model = N.distortion_model_code(config.cam1_distortion_model)
     T_cam0_imu = np.linalg.inv(config.T_imu_cam0)
     T_cam1_imu = np.linalg.inv(config.T_imu_cam1)
     R_cam0_imu, t_cam0_imu = T_cam0_imu[:3, :3], T_cam0_imu[:3, 3]

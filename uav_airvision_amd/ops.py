@@ -117,14 +117,16 @@ def _points_op(fn_name, pts_in, extra, device):
     return out.astype(np.float32) if out_f32 else out
 
 
-def undistort_points(pts_in, intrinsics, distortion_coeffs, rectification_matrix=None, device=0):
-    """cv2.undistortPoints(pts, K, D, None, R, P=I) (reference: camera_model.py:24-47)."""
+def undistort_points(pts_in, intrinsics, distortion_coeffs, rectification_matrix=None, device=0, distortion_model='radtan'):
+    """cv2.undistortPoints(pts, K, D, None, R, P=I) -- or, for distortion_model 'equidistant', cv2.fisheye.undistortPoints(pts, K,
+    D, R, P=I) (reference: camera_model.py:24-47)."""
     R = np.eye(3) if rectification_matrix is None else np.asarray(rectification_matrix, dtype=np.float64)
-    extra = (N.darr(intrinsics), N.darr(distortion_coeffs), N.darr(R.reshape(-1)))
-    return _points_op('av_undistort_points', pts_in, extra, device)
+    extra = (N.darr(intrinsics), N.darr(distortion_coeffs), N.darr(R.reshape(-1)), N.distortion_model_code(distortion_model))
+    return _points_op('av_undistort_points_model', pts_in, extra, device)
 
 
-def distort_points(pts_in, intrinsics, distortion_coeffs, device=0):
-    """cv2.projectPoints(homogeneous(pts), 0, 0, K, D) (reference: camera_model.py:49-75)."""
-    extra = (N.darr(intrinsics), N.darr(distortion_coeffs))
-    return _points_op('av_distort_points', pts_in, extra, device)
+def distort_points(pts_in, intrinsics, distortion_coeffs, device=0, distortion_model='radtan'):
+    """cv2.projectPoints(homogeneous(pts), 0, 0, K, D) -- or cv2.fisheye.distortPoints(pts, K, D) for 'equidistant' (reference:
+    camera_model.py:49-75)."""
+    extra = (N.darr(intrinsics), N.darr(distortion_coeffs), N.distortion_model_code(distortion_model))
+    return _points_op('av_distort_points_model', pts_in, extra, device)
