@@ -1086,6 +1086,25 @@ __device__ __forceinline__ void remove_cam_body(double* P, double* scratch, int 
         P[(size_t)r * ld + c] = scratch[i];
     }
 }
+// Both removals of a pruning step in one pass: rows / columns [s0, s0 + 6) and [s1, s1 + 6) of the n x n matrix leave (s0 < s1, both in the
+// numbering BEFORE the removal).  Entries above and left of s0 stay where they are and are not touched; the rest goes through the
+// scratch copy once instead of twice (dk_finish is a memory-bound kernel: P is 170 KB per stream).
+__device__ __forceinline__ void remove_two_cams_body(double* P, double* scratch, int n, int ld, int s0, int s1)
+{
+    const int tid = threadIdx.x, m = n - 12;
+    for (int i = tid; i < m * m; i += 256) {
+        const int r = i / m, c = i - r * m;
+        if (r < s0 && c < s0) continue;
+        const int sr = r < s0 ? r : (r + 6 < s1 ? r + 6 : r + 12), sc = c < s0 ? c : (c + 6 < s1 ? c + 6 : c + 12);
+        scratch[i] = P[(size_t)sr * ld + sc];
+    }
+    __syncthreads();
+    for (int i = tid; i < m * m; i += 256) {
+        const int r = i / m, c = i - r * m;
+        if (r < s0 && c < s0) continue;
+        P[(size_t)r * ld + c] = scratch[i];
+    }
+}
 __global__ __launch_bounds__(256) void remove_cam_kernel(double* P, double* scratch, int n, int ld, int start) { remove_cam_body(P, scratch, n, ld, start); }
 // batched: two removals per stream, the second index already refers to the matrix after the first removal
 __global__ __launch_bounds__(256) void remove_cam_batch_kernel(const RemArgs* arr)
@@ -1959,7 +1978,8 @@ __device__ __forceinline__ bool chol_packed_lds(double* Lp, int k, int tid)
     }
     return chol_bad == 0;
 }
-__global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict__ arr)
+// k_lo < k <= k_hi: the launch's LDS is sized for k_hi (a launch per length class was tried and lost: msckf_dev_host.inc).
+__global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict__ arr, int k_lo, int k_hi)
 {
     AV_FILTER_PRIO();
     extern __shared__ double Lp[];
@@ -1967,6 +1987,7 @@ __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict
     if (a.m <= 0 || a.mode != 0) return;
     const int tid = threadIdx.x;
     const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
+    if (k <= k_lo || k > k_hi) return;
     auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
     auto stamp = [&](int i) { if (a.prof && tid == 0) a.prof[i] = __builtin_amdgcn_s_memrealtime(); };
     stamp(8);
