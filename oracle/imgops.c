@@ -147,6 +147,10 @@ ORC_API long long orc_lk_stats[3];
  *   status    : [n] u8
  *   eps       : criteria epsilon as passed by the caller (0.01); squared internally like calc()
  * ---------------------------------------------------------------------------------------- */
+/* diagnostic tap (analysis scripts only): iterations run per point and level of the last orc_lk_track call, [n][8]; NULL = off */
+static int* orc_lk_iter_tap = 0;
+ORC_API void orc_lk_set_iter_tap(int* buf) { orc_lk_iter_tap = buf; }
+
 ORC_API void orc_lk_track(int nlev, const uint8_t* const* pyrI, const uint8_t* const* pyrJ,
                           const int* W, const int* H,
                           const float* prev, float* next, uint8_t* status, int n,
@@ -231,6 +235,7 @@ ORC_API void orc_lk_track(int nlev, const uint8_t* const* pyrI, const uint8_t* c
                 iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
                 iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
                 orc_lk_stats[1]++;
+                if (orc_lk_iter_tap && level < 8) orc_lk_iter_tap[8 * p + level] = j + 1;
                 int64_t sb1 = 0, sb2 = 0;
                 for (int y = 0; y < win; ++y)
                     for (int x = 0; x < win; ++x) {
