@@ -57,11 +57,11 @@ bool inflate_all(const uint8_t* z, size_t zn, uint8_t* raw, size_t want)
 {
     const LibDeflate& L = libdeflate();
     if (L.ok) {
-        void* d = L.alloc();
+        static thread_local void* d = nullptr;               // one decompressor per decode thread, kept (libdeflate: not shareable, reusable)
+        if (!d) d = L.alloc();
         if (!d) return false;
         size_t got = 0;
         const int rc = L.zlib_decompress(d, z, zn, raw, want, &got);    // checks the Adler-32; a stream that holds more than `want` fails (no space)
-        L.free_(d);
         return rc == 0 && got == want;
     }
     z_stream zs;
@@ -170,7 +170,8 @@ int decode_one(const char* path, int width, int height, uint8_t* out, char* why,
 {
     FILE* f = fopen(path, "rb");
     if (!f) { snprintf(why, why_cap, "cannot open %s", path); return 2; }
-    std::vector<uint8_t> file;
+    // per-thread buffers that only grow: a fresh 200 KB + 360 KB vector per frame is an mmap, ~140 page faults and a munmap each time
+    static thread_local std::vector<uint8_t> file, raw;
     {
         fseek(f, 0, SEEK_END);
         const long sz = ftell(f);
@@ -219,9 +220,10 @@ int decode_one(const char* path, int width, int height, uint8_t* out, char* why,
     }
     if (n_idat > 1) { z = joined.data(); zn = joined.size(); }
     const size_t pitch = (size_t)width + 1;                      // filter byte + one row of 8-bit grey samples
-    std::vector<uint8_t> raw(pitch * (size_t)height);
+    if (raw.size() < pitch * (size_t)height) raw.resize(pitch * (size_t)height);
+    const size_t raw_bytes = pitch * (size_t)height;
     // complete = the deflate stream ends where it says it does, holds exactly the image and its Adler-32 matches
-    const bool complete = have_hdr && !crc_bad && !order_bad && n_idat > 0 && inflate_all(z, zn, raw.data(), raw.size());
+    const bool complete = have_hdr && !crc_bad && !order_bad && n_idat > 0 && inflate_all(z, zn, raw.data(), raw_bytes);
     if (!complete) { snprintf(why, why_cap, "%s: corrupt or truncated PNG%s", path, crc_bad ? " (chunk CRC mismatch)" : ""); return 2; }
     // un-filter (PNG spec 9.2; bpp = 1): row r of the image lands in out + r * width
     for (int r = 0; r < height; ++r) if (raw[(size_t)r * pitch] > 4) { snprintf(why, why_cap, "%s: bad filter type %d", path, raw[(size_t)r * pitch]); return 2; }
