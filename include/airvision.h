@@ -315,6 +315,10 @@ int  av_msckf_batch_push_imu(av_msckf_batch* b, const int32_t* stream_idx, const
  * synchronised, the capacity grows geometrically (x1.5 at least) and the outgrown allocations stay parked until destroy -- pass
  * the largest cap at the first step (BatchedMSCKF(max_features=...)) when the width of the messages varies.  An explicit
  * rows_cap is never grown: a wider message than it can hold fails with AV_E_CAPACITY.
+ * rows_cap rows are what each stream owns.  The lost features of one frame may need more (a blank frame drops every track at once:
+ * ~4,500 rows at 150 tracks): the device-resident filter then takes the rows from a pool all streams share, allocated behind the
+ * last stream's region -- max(131,072, n_streams * rows_cap) rows of ld doubles, AV_MSCKF_POOL_ROWS overrides -- and stops a
+ * stream that finds the pool exhausted with AV_E_CAPACITY (av_msckf_batch_stream_status).
  * max_cam_states <= 24 (one back-end pass holds 144 columns = 6 per camera state); the reference's value is 20. */
 int  av_msckf_batch_step(av_msckf_batch* b, const int64_t* ids, const double* uv, const int32_t* n_feat, int cap,
                          const double* timestamps, double* out, void* stream);
@@ -352,7 +356,8 @@ int  av_msckf_batch_get_state(av_msckf_batch* b, int stream_idx, double imu32[32
  * concern the whole batch and are returned by the step / wait as before. */
 int  av_msckf_batch_stream_status(av_msckf_batch* b, int stream_idx, int32_t* status, char* msg, int msg_cap);
 /* Run statistics over all streams (drain first): [steps, stream-steps that ran prune_cam_state_buffer (msckf.py:712-786),
- * streams whose lost features were gated in two passes because their candidates outgrew rows_cap, device-buffer
+ * stream-steps whose lost-feature candidates outgrew rows_cap (device-resident filter: rows taken from the shared overflow pool;
+ * AV_MSCKF_STORE=host: gated first, stored in a second pass), device-buffer
  * reallocations after the first step (0 in a correctly pre-sized run), min camera states, max camera states,
  * min map features, max map features].  bench.py uses it to prove that the timed region is the steady state. */
 int  av_msckf_batch_counters(av_msckf_batch* b, int64_t out8[8]);

@@ -272,7 +272,9 @@ class BatchedMSCKF(object):
                      'min_map_features', 'max_map_features')
 
     def counters(self):
-        """Run statistics over all streams (av_msckf_batch_counters); drains the queue first."""
+        """Run statistics over all streams (av_msckf_batch_counters); drains the queue first.  `two_pass_streams` counts the stream-steps
+        whose lost-feature candidates needed more rows than `rows_cap`: the device-resident filter serves them from the overflow pool all
+        streams share (AV_MSCKF_POOL_ROWS; an exhausted pool stops the stream with AV_E_CAPACITY), the host-bookkeeping path in two passes."""
         self.wait(0)
         o = (C.c_int64 * 8)()
         N.check(N.lib().av_msckf_batch_counters(self._h, C.byref(o)))
