@@ -41,6 +41,17 @@ constexpr int IMU_DIM = 21;
 #endif
 #define AV_FILTER_PRIO() __builtin_amdgcn_s_setprio(AV_FILTER_WAVE_PRIO)
 
+// 1 / sqrt(d) for d > 0: the hardware estimate refined by two Newton steps (~1 ulp).  The diagonal block of a panel is a chain of eight
+// square roots and eight reciprocals on ONE thread while 255 wait at the barrier: the library sqrt and the division are ~25 dependent
+// instructions each, this is ~10 for both (sqrt(d) = d * rsqrt(d)).
+__device__ __forceinline__ double av_rsqrt_f64(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
 __device__ __forceinline__ void quat_to_rot(const double* qin, double* R)
 {
     // utils.py:12-23: normalise, R = (2w^2-1) I - 2w [v]x + 2 v v^T
@@ -562,10 +573,11 @@ __device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, d
         for (int i = k + tid; i < R4; i += TEAM) { double v = Hf[i * 3 + k]; part += v * v; }
         double nrm;
         if (TEAM == 256) {
-            red[tid] = part;
+            // wavefront sums by DPP, the four of them through LDS: two barriers (the 256-entry tree took nine per reflector)
+            part = wave_sum_f64(part);
+            if ((tid & 63) == 0) red[tid >> 6] = part;
             team_sync<TEAM>();
-            for (int s2 = 128; s2 > 0; s2 >>= 1) { if (tid < s2) red[tid] += red[tid + s2]; team_sync<TEAM>(); }
-            nrm = sqrt(red[0]);
+            nrm = sqrt((red[0] + red[1]) + (red[2] + red[3]));
             team_sync<TEAM>();
         } else {
             nrm = sqrt(TEAM == 64 ? wave_sum_f64(part) : (TEAM == 16 ? row16_sum_f64(part) : (TEAM == 8 ? row8_sum_f64(part) : quad_sum_f64(part))));
@@ -676,9 +688,10 @@ __device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, d
                     double d = A[j][j];
 #pragma unroll
                     for (int t = 0; t < j; ++t) d -= A[j][t] * A[j][t];
-                    d = sqrt(d);
+                    const double inv = av_rsqrt_f64(d);       // (two Newton steps on the hardware estimate: chol_packed_lds has the reasoning)
+                    d = d * inv;
                     A[j][j] = d;
-                    const double inv = 1.0 / d;
+                    red[j] = inv;                              // reciprocal of the diagonal for the panel rows below
 #pragma unroll
                     for (int i = j + 1; i < NB; ++i) {
                         double v = A[i][j];
@@ -705,7 +718,7 @@ __device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, d
                         double v = x[t];
 #pragma unroll
                         for (int u = 0; u < t; ++u) v -= x[u] * Sg[(j0 + t) * SP + j0 + u];
-                        x[t] = v / Sg[(j0 + t) * SP + j0 + t];
+                        x[t] = v * red[t];
                     }
 #pragma unroll
                     for (int t = 0; t < NB; ++t) if (t < nb) xr[t] = x[t];
@@ -713,24 +726,34 @@ __device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, d
             }
             __syncthreads();
             if (jb < K) {
-                for (int i = jb + ty; i <= K; i += GY) {          // trailing block, border row included (i == K)
+                // trailing block, border row included (i == K); two rows (i, i + GY) per thread and pass share the panel entries of a
+                // column read from LDS (chol_packed_lds: the factorisation is bound by LDS traffic)
+                for (int i = jb + ty; i <= K; i += 2 * GY) {
+                    const int i2 = i + GY;
+                    const bool two = i2 <= K;
                     const double* li = i < K ? Sg + i * SP + j0 : wv + j0;
-                    double lr[NB];
+                    const double* li2 = i2 < K ? Sg + i2 * SP + j0 : wv + j0;
+                    double lr[NB], lr2[NB];
 #pragma unroll
-                    for (int t = 0; t < NB; ++t) lr[t] = t < nb ? li[t] : 0.0;
-                    if (i < K) {
-                        for (int c = jb + tx; c <= i; c += GX) {
-                            double v = Sg[i * SP + c];
+                    for (int t = 0; t < NB; ++t) { lr[t] = t < nb ? li[t] : 0.0; lr2[t] = (two && t < nb) ? li2[t] : 0.0; }
+                    const int ilast = two ? i2 : i, cmax = ilast < K ? ilast : K - 1;     // the border row spans columns jb .. K-1
+                    for (int c = jb + tx; c <= cmax; c += GX) {
+                        double lc[NB];
 #pragma unroll
-                            for (int t = 0; t < NB; ++t) if (t < nb) v -= lr[t] * Sg[c * SP + j0 + t];
-                            Sg[i * SP + c] = v;
+                        for (int t = 0; t < NB; ++t) lc[t] = t < nb ? Sg[c * SP + j0 + t] : 0.0;
+                        if (i == K || c <= i) {
+                            double* dst = i < K ? Sg + i * SP + c : wv + c;
+                            double v = *dst;
+#pragma unroll
+                            for (int t = 0; t < NB; ++t) v -= lr[t] * lc[t];
+                            *dst = v;
                         }
-                    } else {
-                        for (int c = jb + tx; c < K; c += GX) {
-                            double v = wv[c];
+                        if (two) {                                    // (c <= cmax covers row i2's columns exactly)
+                            double* dst = i2 < K ? Sg + i2 * SP + c : wv + c;
+                            double v = *dst;
 #pragma unroll
-                            for (int t = 0; t < NB; ++t) if (t < nb) v -= lr[t] * Sg[c * SP + j0 + t];
-                            wv[c] = v;
+                            for (int t = 0; t < NB; ++t) v -= lr2[t] * lc[t];
+                            *dst = v;
                         }
                     }
                 }
@@ -1914,6 +1937,7 @@ constexpr int CNB = 8;
 __device__ __forceinline__ bool chol_packed_lds(double* Lp, int k, int tid)
 {
     __shared__ int chol_bad;
+    __shared__ double dinv[CNB];                            // reciprocals of the panel's diagonal (the panel rows multiply, they do not divide)
     if (tid == 0) chol_bad = 0;
     auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
     for (int j0 = 0; j0 < k; j0 += CNB) {
@@ -1930,9 +1954,10 @@ __device__ __forceinline__ bool chol_packed_lds(double* Lp, int k, int tid)
 #pragma unroll
                 for (int t = 0; t < j; ++t) d -= A[j][t] * A[j][t];
                 if (!(d > 0.0) || !(d < 1.79e308)) { if (j < nb) chol_bad = 1; d = 1.0; }
-                d = sqrt(d);
+                const double inv = av_rsqrt_f64(d);
+                d = d * inv;
                 A[j][j] = d;
-                const double inv = 1.0 / d;
+                dinv[j] = inv;
 #pragma unroll
                 for (int i = j + 1; i < CNB; ++i) {
                     double v = A[i][j];
@@ -1957,21 +1982,38 @@ __device__ __forceinline__ bool chol_packed_lds(double* Lp, int k, int tid)
                 double v = x[t];
 #pragma unroll
                 for (int u = 0; u < t; ++u) v -= x[u] * at(j0 + t, j0 + u);
-                x[t] = v / at(j0 + t, j0 + t);
+                x[t] = v * dinv[t];
             }
 #pragma unroll
             for (int t = 0; t < CNB; ++t) if (t < nb) at(r, j0 + t) = x[t];
         }
         __syncthreads();
-        for (int r = jb + (tid >> 4); r < k; r += 16) {    // trailing block: A22 -= L21 L21^T (lower triangle)
-            double lr[CNB];
+        // trailing block: A22 -= L21 L21^T (lower triangle).  CTR rows (r, r + 16, ...) per thread and pass: the eight panel entries of a
+        // column are read from LDS once for all of them -- the factorisation is bound by LDS traffic (two workgroups on a CU take twice as
+        // long as one): 8 + 2 CTR LDS operations per 8 CTR multiply-adds where one row at a time made 10 per 8 (659 -> 564 us per
+        // 2,048-stream launch at CTR = 2).
+        constexpr int CTR = 2;                               // (CTR = 4: the same 557 us -- the rest of a panel step is what is left)
+        for (int r0 = jb + (tid >> 4); r0 < k; r0 += 16 * CTR) {
+            double lr[CTR][CNB];
 #pragma unroll
-            for (int t = 0; t < CNB; ++t) lr[t] = t < nb ? at(r, j0 + t) : 0.0;
-            for (int c = jb + (tid & 15); c <= r; c += 16) {
-                double v = at(r, c);
+            for (int u = 0; u < CTR; ++u)
 #pragma unroll
-                for (int t = 0; t < CNB; ++t) if (t < nb) v -= lr[t] * at(c, j0 + t);
-                at(r, c) = v;
+                for (int t = 0; t < CNB; ++t) lr[u][t] = (r0 + 16 * u < k && t < nb) ? at(r0 + 16 * u, j0 + t) : 0.0;
+            const int rlast = min(r0 + 16 * (CTR - 1), k - 1 - ((k - 1 - r0) % 16));       // the last of this thread's rows that exists
+            for (int c = jb + (tid & 15); c <= rlast; c += 16) {
+                double lc[CNB];
+#pragma unroll
+                for (int t = 0; t < CNB; ++t) lc[t] = t < nb ? at(c, j0 + t) : 0.0;
+#pragma unroll
+                for (int u = 0; u < CTR; ++u) {
+                    const int r = r0 + 16 * u;
+                    if (r < k && c <= r) {
+                        double v = at(r, c);
+#pragma unroll
+                        for (int t = 0; t < CNB; ++t) v -= lr[u][t] * lc[t];
+                        at(r, c) = v;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -1991,9 +2033,18 @@ __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict
     auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
     auto stamp = [&](int i) { if (a.prof && tid == 0) a.prof[i] = __builtin_amdgcn_s_memrealtime(); };
     stamp(8);
-    for (int e = tid; e < k * k; e += 256) {
-        const int r = e / k, c = e - r * k;
-        if (c <= r) at(r, c) = a.Sbuf[(size_t)r * a.ld + c];
+    // (four loads in flight per thread: as a plain loop every entry waited for its own round trip -- 20 us of a 90 us workgroup)
+    for (int e0 = tid; e0 < k * k; e0 += 256 * 4) {
+        double v[4]; int idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u, r = e / k, c = e - r * k;
+            const bool ok = e < k * k && c <= r;
+            idx[u] = ok ? r * (r + 1) / 2 + c : -1;
+            v[u] = ok ? a.Sbuf[(size_t)r * a.ld + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (idx[u] >= 0) Lp[idx[u]] = v[u];
     }
     __syncthreads();
     stamp(9);
