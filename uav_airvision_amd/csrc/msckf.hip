@@ -2327,19 +2327,37 @@ template <typename UA> __device__ __forceinline__ void upd_info_body(const UA& a
         for (int q = 0; q < nc; ++q) acc = __builtin_fma(Pc[q * PW_ + c], X[q * W + n], acc);
         a.dx[c] = acc;
     }
-    for (int e = tid; e < n * (n + 1) / 2; e += 256) {
-        int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-        while ((r + 1) * (r + 2) / 2 <= e) ++r;
-        while (r * (r + 1) / 2 > e) --r;
-        const int c = e - r * (r + 1) / 2;
-        double trc = 0, tcr = 0;
+    // 2 x 2 tiles of the lower triangle per thread: eight LDS reads per eight multiply-adds (a pair at a time made two reads per
+    // multiply-add and a double-precision square root per pair for its index)
+    const int nt = (n + 1) / 2;
+    for (int e = tid; e < nt * (nt + 1) / 2; e += 256) {
+        int R = (int)((sqrtf(8.f * e + 1.f) - 1.f) * 0.5f);
+        while ((R + 1) * (R + 2) / 2 <= e) ++R;
+        while (R * (R + 1) / 2 > e) --R;
+        const int C = e - R * (R + 1) / 2, r0 = 2 * R, c0 = 2 * C;
+        double trc[2][2] = {{0, 0}, {0, 0}}, tcr[2][2] = {{0, 0}, {0, 0}};
         for (int q = 0; q < nc; ++q) {
-            trc = __builtin_fma(Pc[q * PW_ + r], X[q * W + c], trc);
-            tcr = __builtin_fma(Pc[q * PW_ + c], X[q * W + r], tcr);
+            const double pr[2] = {Pc[q * PW_ + r0], Pc[q * PW_ + r0 + 1]}, xc[2] = {X[q * W + c0], X[q * W + c0 + 1]};
+            const double pc[2] = {Pc[q * PW_ + c0], Pc[q * PW_ + c0 + 1]}, xr[2] = {X[q * W + r0], X[q * W + r0 + 1]};
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    trc[i][j] = __builtin_fma(pr[i], xc[j], trc[i][j]);
+                    tcr[i][j] = __builtin_fma(pc[j], xr[i], tcr[i][j]);
+                }
         }
-        const double v = ((a.P[(size_t)r * a.ld + c] - trc) + (a.P[(size_t)c * a.ld + r] - tcr)) / 2.;
-        a.P[(size_t)r * a.ld + c] = v;
-        a.P[(size_t)c * a.ld + r] = v;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = r0 + i, c = c0 + j;
+                if (r < n && c <= r) {                       // (c <= r < n; the upper entries of a diagonal tile belong to their mirror)
+                    const double v = ((a.P[(size_t)r * a.ld + c] - trc[i][j]) + (a.P[(size_t)c * a.ld + r] - tcr[i][j])) / 2.;
+                    a.P[(size_t)r * a.ld + c] = v;
+                    a.P[(size_t)c * a.ld + r] = v;
+                }
+            }
     }
     stamp(7);
 }
