@@ -599,6 +599,29 @@ __device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, d
             for (int i = k + 1; i < R4; ++i) col[i * stride] -= dot * Hf[i * 3 + k];
         };
         const int nfix = (2 - k) + 1, njobs = nfix + R4;
+        // workgroup teams (long tracks): FOUR lanes per column, each a quarter of the rows, the partial products summed inside the quad
+        // (DPP): a column of 80 rows walked by one thread was 4 us per application with two thirds of the workgroup idle
+        auto reflect4 = [&](double* col, int stride, int part) {
+            const int len = R4 - k, chunk = (len + 3) >> 2, i0 = k + part * chunk, i1 = min(R4, i0 + chunk);
+            double dot = 0;
+#pragma unroll 5
+            for (int i = i0; i < i1; ++i) dot += (i == k ? v0 : Hf[i * 3 + k]) * col[i * stride];       // unrolled: the LDS loads of five rows are in flight together
+            dot = quad_sum_f64(dot) * tau;
+#pragma unroll 5
+            for (int i = i0; i < i1; ++i) col[i * stride] -= dot * (i == k ? v0 : Hf[i * 3 + k]);
+        };
+        if (TEAM == 256) {
+            for (int job = tid >> 2; job < ((njobs + 63) & ~63); job += 64) {       // (whole quads run the DPP sum: the bound is rounded up)
+                double* col = rr; int stride = 1;
+                const bool on = job < njobs;
+                if (on) {
+                    if (job < 2 - k) { col = Hf + (k + 1 + job); stride = 3; }
+                    else if (job < nfix) { col = rr; stride = 1; }
+                    else { col = S + (job - nfix); stride = SP; }
+                }
+                if (on) reflect4(col, stride, tid & 3);
+            }
+        } else
         for (int job = tid; job < njobs; job += TEAM) {
             // one call site: the lanes of a wavefront differ only in (column, stride), not in control flow
             double* col; int stride;
@@ -608,6 +631,9 @@ __device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, d
             reflect(col, stride);
         }
         team_sync<TEAM>();
+        if (TEAM == 256) {
+            for (int job = tid >> 2; job < R4; job += 64) reflect4(S + job * SP, 1, tid & 3);       // ... and G from the right
+        } else
         for (int job = tid; job < R4; job += TEAM) reflect(S + job * SP, 1);       // ... and G from the right
         team_sync<TEAM>();
     }
