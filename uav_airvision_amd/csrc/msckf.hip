@@ -46,11 +46,15 @@ constexpr int IMU_DIM = 21;
 // instructions each, this is ~10 for both (sqrt(d) = d * rsqrt(d)).
 __device__ __forceinline__ double av_rsqrt_f64(double d)
 {
-    double y = __builtin_amdgcn_rsq(d);
-    const double h = 0.5 * d;
+    // (pivots below 1e-280 -- the 1e-300 floor of the Gram regularisation, or a denormal -- are scaled into range first: the hardware
+    //  estimate of a denormal is not usable and y * y would overflow)
+    const bool tiny = d < 1e-280;
+    const double ds = tiny ? d * 0x1p200 : d;
+    double y = __builtin_amdgcn_rsq(ds);
+    const double h = 0.5 * ds;
     y = y * (1.5 - h * y * y);
     y = y * (1.5 - h * y * y);
-    return y;
+    return tiny ? y * 0x1p100 : y;
 }
 __device__ __forceinline__ void quat_to_rot(const double* qin, double* R)
 {
