@@ -1858,11 +1858,15 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // LDS (two LDS buffers, one barrier per panel).  The un-pipelined form (load, barrier, multiply, barrier) paid one full global-memory
 // latency per panel -- PMC, round 4: the tile kernels waited 77-79 % of their wave cycles and issued VALU in 9 %.
 // The caller separates consecutive calls by a barrier.
+// rlim / clim: outputs at or beyond them are never used -- a thread whose whole 4 x 4 sub-tile lies outside multiplies nothing (it still
+// stages its share of the panels).  Rows map to wavefronts (ty = tid / 16: four rows of sub-tiles per wavefront), so the 13 valid rows of
+// the third row of tiles of a 141-row product cost one wavefront's multiply-adds instead of four.
 template <typename FA, typename FB>
-__device__ __forceinline__ void gemm_tile64(int Q, int r0, int c0, FA loadA, FB loadB, double (&acc)[4][4])
+__device__ __forceinline__ void gemm_tile64(int Q, int r0, int c0, FA loadA, FB loadB, double (&acc)[4][4], int rlim = 1 << 30, int clim = 1 << 30)
 {
     __shared__ __attribute__((aligned(16))) double pa[2][GQ * GP], pb[2][GQ * GP];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const bool active = r0 + 4 * ty < rlim && c0 + 4 * tx < clim;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1888,14 +1892,16 @@ __device__ __forceinline__ void gemm_tile64(int Q, int r0, int c0, FA loadA, FB 
         }
         if (q0 + GQ < Q) fetch(q0 + GQ);                   // in flight during the products below
         lds_barrier();
+        if (active) {
 #pragma unroll
-        for (int q = 0; q < GQ; ++q) {
-            const av_d4 av = *reinterpret_cast<const av_d4*>(&pa[buf][q * GP + 4 * ty]);
-            const av_d4 bv = *reinterpret_cast<const av_d4*>(&pb[buf][q * GP + 4 * tx]);
+            for (int q = 0; q < GQ; ++q) {
+                const av_d4 av = *reinterpret_cast<const av_d4*>(&pa[buf][q * GP + 4 * ty]);
+                const av_d4 bv = *reinterpret_cast<const av_d4*>(&pb[buf][q * GP + 4 * tx]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(av[i], bv[j], acc[i][j]);
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(av[i], bv[j], acc[i][j]);
+            }
         }
         buf ^= 1;
     }
@@ -1914,7 +1920,7 @@ __global__ __launch_bounds__(256) void upd_tt_kernel(const UpdArgs* __restrict__
     double acc[4][4];
     gemm_tile64(a.nc, r0, c0,
                 [&](int q, int c) { return c < n ? AV_GD(a.P)[(size_t)AV_GI(a.cols)[q] * a.ld + c] : 0.0; },
-                [&](int q, int r) { return r < k ? AV_GD(a.W)[(size_t)q * ldt + r] : 0.0; }, acc);
+                [&](int q, int r) { return r < k ? AV_GD(a.W)[(size_t)q * ldt + r] : 0.0; }, acc, n, k);
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1941,7 +1947,7 @@ __global__ __launch_bounds__(256) void upd_s_kernel(const UpdArgs* __restrict__ 
     double acc[4][4];
     gemm_tile64(a.nc, r0, c0,
                 [&](int q, int r) { return r < k ? AV_GD(a.T)[(size_t)AV_GI(a.cols)[q] * a.ld + r] : 0.0; },
-                [&](int q, int c) { return c < k ? AV_GD(a.W)[(size_t)q * ldt + c] : 0.0; }, acc);
+                [&](int q, int c) { return c < k ? AV_GD(a.W)[(size_t)q * ldt + c] : 0.0; }, acc, k, k);
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -2164,7 +2170,7 @@ __global__ __launch_bounds__(256) void upd_p_kernel(const UpdArgs* __restrict__ 
     double t[4][4];
     gemm_tile64(k, r0, c0,
                 [&](int q, int r) { return r < n ? AV_GD(a.Kt)[(size_t)q * a.ld + r] : 0.0; },
-                [&](int q, int c) { return c < n ? AV_GD(a.Kt)[(size_t)q * a.ld + c] : 0.0; }, t);
+                [&](int q, int c) { return c < n ? AV_GD(a.Kt)[(size_t)q * a.ld + c] : 0.0; }, t, n, n);
     if (blockIdx.x == 0) {                                   // delta_x = Y^T y_r, by the stream's first tile
         const auto rcol = a.W + (size_t)a.nc * a.ldt;
         for (int c = threadIdx.x; c < n; c += 256) {
@@ -2509,7 +2515,7 @@ template <typename UA> __device__ __forceinline__ void upd_gram_one(const UA& a)
         return c < nc ? AV_GD(a.Hsrc)[sr * a.ld + AV_GI(a.cols)[c]] : AV_GD(a.rsrc)[sr];
     };
     double acc[4][4];
-    gemm_tile64(rows, r0, c0, elem, elem, acc);
+    gemm_tile64(rows, r0, c0, elem, elem, acc, k1, k1);
     const auto slab = a.W + (size_t)blockIdx.y * k1 * k1;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 #pragma unroll
