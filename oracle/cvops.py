@@ -92,7 +92,12 @@ def calc_optical_flow_pyr_lk(prev_img, next_img, prev_pts, next_pts, winSize=(15
         return nxt, status, None
     pI = _cached_pyramid(prev_img, maxLevel, cache_pyramids)
     pJ = _cached_pyramid(next_img, maxLevel, cache_pyramids)
-    nlev = maxLevel + 1
+    # cv::buildOpticalFlowPyramid (OpenCV 4.x lkpyramid.cpp) returns the last level whose successor is still larger than the
+    # window in both dimensions; level 0 is always used.  Not reached at 752 x 480, winSize 15, maxLevel 3.
+    nlev = 1
+    while nlev <= maxLevel and pI[nlev].shape[1] > winSize[0] and pI[nlev].shape[0] > winSize[1]:
+        nlev += 1
+    pI, pJ = pI[:nlev], pJ[:nlev]
     PI = (C.POINTER(C.c_uint8) * nlev)(*[_u8p(a) for a in pI])
     PJ = (C.POINTER(C.c_uint8) * nlev)(*[_u8p(a) for a in pJ])
     W = (C.c_int * nlev)(*[a.shape[1] for a in pI])

@@ -75,7 +75,7 @@ def test_lk_stereo_and_edge_cases_bit_exact(ops, frames0, cfg):
     assert np.array_equal(p_gpu.view(np.uint32), p_cpu.view(np.uint32))
 
 
-@pytest.mark.parametrize('win,max_level', [(9, 3), (21, 3), (31, 2), (16, 1), (5, 4), (15, 1), (15, 4)])
+@pytest.mark.parametrize('win,max_level', [(9, 3), (21, 3), (31, 2), (16, 1), (5, 4), (15, 1), (15, 4), (29, 4), (31, 4)])
 def test_lk_other_windows_and_levels_bit_exact(ops, frames0, win, max_level):
     """config.win_size / pyramid levels other than the reference's defaults (config.py:31-44 are configuration, not constants):
     windows other than 15 take the general one-wavefront-per-point kernel, 15 x 15 with another maxLevel the 16-lane kernel.
@@ -95,6 +95,26 @@ def test_lk_other_windows_and_levels_bit_exact(ops, frames0, win, max_level):
         assert np.array_equal(s_gpu, s_cpu), (win, max_level, int((s_gpu != s_cpu).sum()))
         assert 50 < s_cpu.sum() < len(prev)
         assert np.array_equal(p_gpu.view(np.uint32), p_cpu.view(np.uint32)), (win, max_level, np.abs(p_gpu - p_cpu).max())
+
+
+@pytest.mark.parametrize('w,h,win,max_level', [(18, 20, 31, 2), (40, 36, 21, 2), (33, 17, 15, 1), (64, 48, 23, 1)])
+def test_lk_small_images_bit_exact(ops, w, h, win, max_level):
+    """Images barely larger than -- or smaller than -- the window: windows reach more than one image width past the border (the
+    border interpolation has to loop like cv::borderInterpolate) and the levels OpenCV would not build are dropped on both sides
+    ((29, 4) / (31, 4) above: the 47 x 30 top level is kept at win 29 and dropped at win 31)."""
+    from oracle import cvops
+    rng = np.random.default_rng(w * 100 + h)
+    I = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    I = ((I.astype(np.int32) + np.roll(I, 1, 0) + np.roll(I, 1, 1) + np.roll(I, (1, 1), (0, 1))) // 4).astype(np.uint8)
+    J = np.roll(I, (1, -1), (0, 1))
+    prev = np.stack([rng.uniform(-4, w + 4, 80), rng.uniform(-4, h + 4, 80)], 1).astype(np.float32)
+    init = prev + rng.normal(0, 1.5, prev.shape).astype(np.float32)
+    kw = dict(winSize=(win, win), maxLevel=max_level, criteria=(3, 30, 0.01), flags=4, minEigThreshold=1e-4)
+    p_gpu, s_gpu, _ = ops.calc_optical_flow_pyr_lk(I, J, prev, init, **kw)
+    p_cpu, s_cpu, _ = cvops.calc_optical_flow_pyr_lk(I, J, prev, init, **kw)
+    assert np.array_equal(s_gpu, s_cpu), int((s_gpu != s_cpu).sum())
+    assert s_cpu.sum() > 0
+    assert np.array_equal(p_gpu.view(np.uint32), p_cpu.view(np.uint32)), np.abs(p_gpu - p_cpu).max()
 
 
 def test_lk_flat_image_fails_min_eig(ops, cfg):

@@ -54,6 +54,15 @@ __device__ __forceinline__ int av_reflect101(int p, int len)
     if (p >= len) p = 2 * len - 2 - p;
     return p;
 }
+// the same for any overshoot (cv::borderInterpolate loops): the general LK kernel's windows reach win + 1 pixels past a level
+// that may be only win + 1 pixels wide
+__device__ __forceinline__ int av_reflect101_any(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do { p = p < 0 ? -p : 2 * len - 2 - p; } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
 
 // cv2.undistortPoints core: 5 fixed-point iterations of the radtan inverse, then R*[x y 1].
 // Expression order follows OpenCV's cvUndistortPointsInternal; fp64, no contraction.

@@ -550,7 +550,7 @@ __device__ __forceinline__ long long wave_sum_i64(long long v)
 }
 
 struct LKLevel { const uint8_t* base; int pitch, w, h; };      // base = address of pixel (0, 0)
-__device__ __forceinline__ int lkg_pix(const LKLevel& L, int x, int y) { return L.base[(size_t)av_reflect101(y, L.h) * L.pitch + av_reflect101(x, L.w)]; }
+__device__ __forceinline__ int lkg_pix(const LKLevel& L, int x, int y) { return L.base[(size_t)av_reflect101_any(y, L.h) * L.pitch + av_reflect101_any(x, L.w)]; }
 
 __global__ __launch_bounds__(256) void lk_track_generic_kernel(LKArgs a, int WIN)
 {
@@ -697,6 +697,11 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
     if (p.win < 3 || p.win > LKG_MAX_WIN) { av_set_error("av_lk_track: winSize %d outside 3 .. %d", p.win, LKG_MAX_WIN); return AV_E_INVALID; }
     LKArgs a;
     a.pyrI = pyrI; a.pyrJ = pyrJ; a.stream_stride = stream_stride; a.g = g;
+    // cv::buildOpticalFlowPyramid stops at the first level whose successor would be no larger than the window in either
+    // dimension (OpenCV 4.x lkpyramid.cpp: `if (sz.width <= winSize.width || sz.height <= winSize.height) return level`);
+    // level 0 is always tracked.  Not reached by the reference's 752 x 480 / 15 / 3.
+    for (int l = 1; l < a.g.levels; ++l)
+        if (a.g.w[l] <= p.win || a.g.h[l] <= p.win) { a.g.levels = l; break; }
     a.prev = prev; a.next = next; a.status = status; a.count = count; a.index = index; a.cap = cap;
     a.max_iter = p.max_iter; a.eps2 = p.eps2; a.min_eig = p.min_eig;
     a.imgI = imgI; a.imgJ = imgJ; a.imgI_stride = imgI_stride; a.imgJ_stride = imgJ_stride;

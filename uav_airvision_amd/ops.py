@@ -61,6 +61,12 @@ def calc_optical_flow_pyr_lk(prev_img, next_img, prev_pts, next_pts, winSize=(15
     if n == 0:
         return nxt.copy(), np.zeros((0, 1), np.uint8), None
     imgs = np.stack([np.asarray(prev_img, dtype=np.uint8), np.asarray(next_img, dtype=np.uint8)])
+    # levels OpenCV would not build are not laid out either (cv::buildOpticalFlowPyramid stops before the first level that is
+    # no larger than the window; av_lk_track applies the same rule to whatever it is handed)
+    lw, lh, eff = imgs.shape[2], imgs.shape[1], 0
+    while eff < maxLevel and (lw + 1) // 2 > winSize[0] and (lh + 1) // 2 > winSize[1]:
+        lw, lh, eff = (lw + 1) // 2, (lh + 1) // 2, eff + 1
+    maxLevel = eff
     pyr, lay = build_pyramids(imgs, maxLevel + 1, device)
     dev = _dev(device)
     d_prev = torch.from_numpy(prev).to(dev)
