@@ -176,6 +176,28 @@ int av_frontend_step(av_frontend* fe, const uint8_t* img0_dev, const uint8_t* im
 int av_frontend_step_host(av_frontend* fe, const uint8_t* img0_host, const uint8_t* img1_host, int64_t img_stride,
                           const double* timestamps, void* stream);
 
+/* Shared frame store -- for sweeps that replay the SAME frames on several streams: the reference's run.bat:4-12 runs every
+ * sequence from several start offsets, and an offset only moves the start index (streaming/dataset.py:206-214), so every frame
+ * of the sequence is read by every offset stream a few steps apart.  A frame put into the store is copied to the device, gets
+ * both its pyramids (levels 1.., level 0 is read in place) and its FAST pass ONCE (the detector's lists are independent of the
+ * stream: the per-stream mask of feature_adder.py:56-62 is applied when the lists are binned into a stream's cells); the streams
+ * only carry an entry number per step.
+ *   av_frontend_frames_reserve   allocate n_slots entries (~2 MB each at 752 x 480 and four levels); once per engine.
+ *   av_frontend_frames_upload    n host frame pairs (frame i: img0_host + i*img_stride, img1_host + i*img_stride, tightly packed
+ *                                width*height u8) into entries slots[i].  The copies and kernels run on the engine's copy stream,
+ *                                behind the newest step ENQUEUED so far (the entries must be free as of that step) and beside
+ *                                whatever is enqueued afterwards: upload the frames of step k+1 before enqueueing step k to overlap
+ *                                the two.  The host arrays are free again when the call returns.
+ *   av_frontend_step_frames      av_frontend_step with stream s reading entry slot_of_stream[s] (its previous frame's entry is
+ *                                remembered by the engine and must still hold that frame).  A NEGATIVE entry = the stream has no
+ *                                frame in this step (its sequence is over): none of its kernels' workgroups do anything, its
+ *                                published count reads 0, its state stays as it is.  Results are bit-identical to av_frontend_step
+ *                                on the same images. */
+int av_frontend_frames_reserve(av_frontend* fe, int n_slots);
+int av_frontend_frames_upload(av_frontend* fe, const int32_t* slots, int n, const uint8_t* img0_host, const uint8_t* img1_host,
+                              int64_t img_stride, void* stream);
+int av_frontend_step_frames(av_frontend* fe, const int32_t* slot_of_stream, const double* timestamps, void* stream);
+
 /* Host-side staging for sweeps: decode n 8-bit greyscale, non-interlaced PNG files of width x height (the EuRoC camera
  * frames; reference: streaming/dataset.py:101 `cv2.imread(path, -1)` on the reader threads of dataset.py:93-158) on
  * `threads` host threads, file i into out + i*out_stride -- e.g. straight into the [S][h][w] batches handed to

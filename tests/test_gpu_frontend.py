@@ -301,3 +301,65 @@ def test_step_host_double_buffering_matches_resident_inputs(cfg):
         for s in range(S):
             assert len(a[k][s][0]) > 20
             assert np.array_equal(a[k][s][0], b[k][s][0]) and np.array_equal(a[k][s][1].view(np.uint64), b[k][s][1].view(np.uint64)), (k, s)
+
+
+def test_shared_frame_store_matches_per_stream_steps_and_idles_finished_streams(cfg):
+    """run.bat:4-12 replays one sequence from several start offsets (dataset.py:206-214 only moves the start index): the streams
+    read the SAME frames a few steps apart.  `frames_upload` puts every distinct frame into the device store once (copy, pyramids,
+    FAST), `step_frames` hands each stream its entry; the result must be bit-identical to `step_host` fed the per-stream images,
+    frame by frame, and a stream whose sequence is over (entry -1) publishes nothing while the others go on -- also when a store
+    entry is REUSED for a later frame (the store below has fewer entries than the sequence has frames)."""
+    from uav_airvision_amd.euroc import SharedFramePlan
+    from uav_airvision_amd.frontend import FrontendEngine
+    from uav_airvision_amd.synth import SyntheticStream
+    NF = 14
+    st = SyntheticStream(cfg, seed=5, n_frames=NF)
+    frames = [st.frame(k) for k in range(NF)]
+    imu = list(st.imu)
+    starts = [0, 2, 5]
+
+    class Seq(object):                     # what SharedFramePlan needs of a dataset: (timestamp, cam0 key, cam1 key) per frame
+        def __init__(self, s0):
+            self.stereo_files = [(frames[f].timestamp, 'cam0/%d' % f, 'cam1/%d' % f) for f in range(s0, NF)]
+    plan = SharedFramePlan([Seq(s0) for s0 in starts])
+    assert plan.n_steps == NF and plan.n_frames_distinct == NF and plan.n_slots < NF        # entries are recycled
+    S = len(starts)
+    ref = FrontendEngine(cfg, n_streams=S)
+    eng = FrontendEngine(cfg, n_streams=S)
+    eng.frames_reserve(plan.n_slots)
+    last = [-1e9] * S
+
+    def upload(k):
+        new = plan.new[k]
+        fr = [int(p0.split('/')[1]) for _e, p0, _p1 in new]
+        eng.frames_upload(np.array([e for e, _a, _b in new], np.int32), np.stack([frames[f].cam0_image for f in fr]), np.stack([frames[f].cam1_image for f in fr]))
+    upload(0)
+    for k in range(plan.n_steps):
+        if k + 1 < plan.n_steps and plan.new[k + 1]:
+            upload(k + 1)                  # before step k is enqueued: the protocol that overlaps the two (airvision.h)
+        img0 = np.zeros((S, eng.height, eng.width), np.uint8); img1 = np.zeros_like(img0)
+        ts = np.zeros(S)
+        for s in range(S):
+            f = starts[s] + k
+            if f < NF:
+                img0[s] = frames[f].cam0_image; img1[s] = frames[f].cam1_image; ts[s] = frames[f].timestamp
+                assert plan.ts[k, s] == ts[s] and plan.slots[k, s] >= 0
+                for m in imu:
+                    if last[s] < m.timestamp <= ts[s]:
+                        ref.push_imu(s, m.timestamp, m.angular_velocity); eng.push_imu(s, m.timestamp, m.angular_velocity)
+                last[s] = ts[s]
+            else:
+                assert plan.slots[k, s] == -1
+                ts[s] = last[s] + 0.05 * (f - NF + 1)
+        ref.step_host(img0, img1, ts)
+        eng.step_frames(plan.slots[k], ts)
+        a, b = ref.read_features(), eng.read_features()
+        for s in range(S):
+            if plan.slots[k, s] < 0:
+                assert len(b[s][0]) == 0, (k, s)
+                continue
+            assert len(b[s][0]) >= 40
+            assert np.array_equal(a[s][0], b[s][0]), (k, s)
+            assert np.array_equal(a[s][1].view(np.uint64), b[s][1].view(np.uint64)), (k, s)
+            assert ref.read_counters(s) == eng.read_counters(s), (k, s)
+    ref.close(); eng.close()

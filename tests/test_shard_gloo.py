@@ -117,6 +117,49 @@ def test_two_rank_gloo_gathers_eight_ragged_sequence_trajectories():
     assert len(set(s[0] for s in sh0)) == 8 and all(s[1] == 8 for s in sh0)        # eight different lengths
 
 
+def _worker_report(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from uav_airvision_amd import shard
+    from uav_airvision_amd.sweep import sweep_report
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    jobs = shard.broadcast_object([('MH_03_medium', float(o)) for o in range(5)] if rank == 0 else None)
+    mine = shard.partition(len(jobs), world, rank)
+    # what a rank's sweep produced for its own streams: per-stream ATE / RTE and the batch statistics
+    report = {j: dict(sequence=jobs[j][0], offset=jobs[j][1], frames=100 + j, ate_rmse=0.01 * (j + 1), ate_mean=0.005, rte_rmse=0.002) for j in mine if j != 3}
+    stats = {'seconds': 2.0 + rank, 'stream_frames': sum(100 + j for j in mine), 'steps': 104, 'frames_decoded': 110 + rank}
+    elapsed = shard.max_over_ranks(2.5 + rank)
+    per_rank = shard.gather_objects({'rank': rank, 'streams': [jobs[j] for j in mine], 'report': report, 'stats': stats})
+    q.put((rank, sweep_report(jobs, per_rank, elapsed, world)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sweep_report_is_one_aggregate_line():
+    """configs[3] / [4] are defined by "aggregate frames/sec + per-seq ATE": the per-rank reports and batch statistics are gathered
+    (shard.gather_objects) and `sweep.sweep_report` builds ONE line -- stream-frames of all ranks over the slowest rank's time, every
+    stream's ATE in job order (a stream too short for an ATE still has its row) -- identical on every rank; rank 0 prints it."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_report, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_r0, rep0), (_r1, rep1) = res
+    assert rep0 == rep1
+    assert rep0['n_gpus'] == 2 and rep0['streams'] == [['MH_03_medium', float(o)] for o in range(5)] and rep0['streams_per_rank'] == [3, 2]
+    assert rep0['stream_frames'] == 100 + 101 + 102 + 103 + 104 and rep0['frames_decoded'] == 221
+    assert abs(rep0['seconds'] - 3.5) < 1e-12 and abs(rep0['value'] - 510 / 3.5) < 1e-9          # the slower rank's clock
+    assert [r['offset'] for r in rep0['report']] == [0.0, 1.0, 2.0, 3.0, 4.0]
+    assert rep0['report'][3]['frames'] == 0 and 'ate_rmse' not in rep0['report'][3]
+    assert abs(rep0['report'][4]['ate_rmse'] - 0.05) < 1e-12 and rep0['report'][4]['frames'] == 104
+
+
 def test_bench_self_launches_its_ranks_without_torchrun():
     """`python bench.py --gpus 2` with no torchrun environment: the parent starts one child per rank before anything touches
     a GPU, the ranks broadcast the run configuration, partition the streams, take the max-over-ranks time and the

@@ -205,3 +205,64 @@ def test_frame_stager_steps_ragged_streams_in_order(tmp_path, cfg):
     stg = FrameStager(dss, 480, 752, max_frames=2)
     assert stg.next() is not None and stg.next() is not None and stg.next() is None
     stg.close()
+
+
+def _fake_datasets(starts, n, seq='A'):
+    class D(object):
+        def __init__(self, s0):
+            self.stereo_files = [(1.0 + 0.05 * k, '%s/cam0/%d.png' % (seq, k), '%s/cam1/%d.png' % (seq, k)) for k in range(s0, n)]
+    return [D(s0) for s0 in starts]
+
+
+@pytest.mark.parametrize('starts,n', [([0, 20, 40, 60, 80, 100, 120, 140], 200), ([0, 0, 7, 7, 3], 40), ([5], 30), ([0, 1, 2, 3], 4)])
+def test_shared_frame_plan_decodes_every_frame_once_and_never_rewrites_a_live_entry(starts, n):
+    """The offset sweep's frame sharing (run.bat:4-12, dataset.py:206-214): every distinct frame appears in exactly one `new` list,
+    every stream finds its current AND its previous frame in the entry the plan names, and an entry is handed to a new frame no
+    earlier than two steps after its last reader (the upload of step k + 1 is issued before step k is enqueued and waits for step k - 1)."""
+    from uav_airvision_amd.euroc import SharedFramePlan
+    dss = _fake_datasets(starts, n) + (_fake_datasets([0, 2], max(n // 2, 3), seq='B') if len(starts) > 2 else [])      # a second sequence shares nothing
+    plan = SharedFramePlan(dss)
+    files = [d.stereo_files for d in dss]
+    assert plan.n_steps == max(len(f) for f in files)
+    keys = [(p0, p1) for k in range(plan.n_steps) for _e, p0, p1 in plan.new[k]]
+    assert len(keys) == len(set(keys)) == plan.n_frames_distinct == len({(p0, p1) for f in files for _t, p0, p1 in f})
+    assert plan.n_stream_frames == sum(len(f) for f in files)
+    holds, last_read = {}, {}                     # entry -> key it holds; entry -> last step that read it
+    for k in range(plan.n_steps):
+        for e, p0, p1 in plan.new[k]:
+            assert 0 <= e < plan.n_slots
+            assert last_read.get(e, -10) <= k - 2, (k, e)
+            holds[e] = (p0, p1)
+        for s, f in enumerate(files):
+            if k >= len(f):
+                assert plan.slots[k, s] == -1 and plan.ts[k, s] == -1.0
+                continue
+            t, p0, p1 = f[k]
+            e = int(plan.slots[k, s])
+            assert holds[e] == (p0, p1) and plan.ts[k, s] == t
+            last_read[e] = k
+            if k > 0:
+                ep = int(plan.slots[k - 1, s])
+                assert holds[ep] == (f[k - 1][1], f[k - 1][2]), 'the previous frame of stream %d was overwritten before step %d' % (s, k)
+                last_read[ep] = k
+    live = max(len(set(int(e) for e in plan.slots[k] if e >= 0) | set(int(e) for e in plan.slots[k - 1] if e >= 0 and k > 0)) for k in range(plan.n_steps))
+    assert live <= plan.n_slots <= plan.n_frames_distinct
+
+
+def test_shared_frame_stager_decodes_the_new_frames_of_each_step(tmp_path, cfg):
+    from uav_airvision_amd.euroc import EuRoCDataset, SharedFramePlan, SharedFrameStager, read_image, write_euroc_layout
+    from uav_airvision_amd.synth import SyntheticStream
+    root = str(tmp_path / 'SEQ')
+    write_euroc_layout(root, SyntheticStream(cfg, seed=2, n_frames=6), compress_level=1)
+    dss = []
+    for off in (0.0, 0.1):
+        d = EuRoCDataset(root); d.set_starttime(off); dss.append(d)
+    plan = SharedFramePlan(dss, max_frames=5)
+    assert plan.n_steps == 5 and [len(x) for x in plan.new] == [2, 2, 1, 1, 0] and plan.n_stream_frames == 9
+    stg = SharedFrameStager(plan, 480, 752, threads=2)
+    for k in range(plan.n_steps):
+        ent, i0, i1 = stg.get(k)
+        assert ent.tolist() == [e for e, _a, _b in plan.new[k]] and i0.shape == (len(ent), 480, 752) == i1.shape
+        for j, (_e, p0, p1) in enumerate(plan.new[k]):
+            assert np.array_equal(i0[j], read_image(p0)) and np.array_equal(i1[j], read_image(p1))
+    stg.close()

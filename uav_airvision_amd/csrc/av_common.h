@@ -156,8 +156,9 @@ __device__ __forceinline__ void av_distort(const CamModel& c, double x, double y
 // pyramid.hip
 int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stride, int n_streams, int imgs_per_stream,
                       const PyrGeom& g, uint8_t* pyr_base, int64_t stream_stride, int64_t slot_stride, int slot0, int slot1,
-                      hipStream_t st, bool write_level0 = true, bool* wrote_level0 = nullptr);
+                      hipStream_t st, bool write_level0 = true, bool* wrote_level0 = nullptr, const int* index = nullptr);
 // write_level0 = false: levels 1.. only, level 0 stays the caller's image (honoured by the fused kernel; *wrote_level0 tells)
+// index (device, n_streams ints): image group i reads / writes storage entry index[i] of the image and pyramid arrays
 
 // lk.hip
 struct LKParams {
@@ -167,7 +168,8 @@ struct LKParams {
 int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride, int n_set, const PyrGeom& g,
                  const float* prev, float* next, uint8_t* status, const int* count, int cap, int launch_pts,
                  const LKParams& p, hipStream_t st, const int* index = nullptr,
-                 const uint8_t* imgI = nullptr, int64_t imgI_stride = 0, const uint8_t* imgJ = nullptr, int64_t imgJ_stride = 0);      // level 0 of I / J from the caller's image (lk.hip: LKArgs)
+                 const uint8_t* imgI = nullptr, int64_t imgI_stride = 0, const uint8_t* imgJ = nullptr, int64_t imgJ_stride = 0,      // level 0 of I / J from the caller's image (lk.hip: LKArgs)
+                 const int* mapI = nullptr, const int* mapJ = nullptr);      // set -> storage entry of the I / J pyramids and images (shared frame store)
 
 // fast.hip
 void av_fast_tiles(int w, int h, int* tiles, int* tile_cap);         // tile count of a w x h image, entries per tile list
@@ -175,4 +177,4 @@ int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, int bo
                    int n_img, int w, int h, int threshold,
                    uint32_t* kp, int* count, int cap,                               // flat output (ops API) or NULL
                    uint32_t* tile_kp, int* tile_count,                              // per-tile output (front-end engine) or NULL
-                   int* overflow, int stat_stride, hipStream_t st);
+                   int* overflow, int stat_stride, hipStream_t st, const int* index = nullptr);      // index: image i of the launch is storage entry index[i]

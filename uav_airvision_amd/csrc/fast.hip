@@ -49,6 +49,7 @@ struct FastArgs {
     int* overflow; int stat_stride;
     int dbg;
     int n_img, tiles_x, tiles_y;                 // XCD-aware 1-D launch when tiles_x > 0 (fast_kernel)
+    const int* index;                            // optional: image i of the launch is storage entry index[i] (shared frame store)
 };
 
 // Corner score of one candidate, the 16 ring differences two to a register (packed 16-bit lanes: ring position j in the low
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
         const int t = j % per;
         by = t / a.tiles_x; bx = t - by * a.tiles_x;
     } else { img_i = blockIdx.z; bx = blockIdx.x; by = blockIdx.y; }
+    if (a.index) img_i = a.index[img_i];                     // storage entry of this image (shared frame store): image, mask and lists
     const uint8_t* img = a.img + img_i * a.img_stride;
     const int x0 = bx * TW, y0 = by * TH;
     const int tid = threadIdx.x;
@@ -303,7 +305,7 @@ void av_fast_tiles(int w, int h, int* tiles, int* tile_cap)
 int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, int border, const uint8_t* mask, int64_t mask_stride,
                    int n_img, int w, int h, int threshold,
                    uint32_t* kp, int* count, int cap, uint32_t* tile_kp, int* tile_count,
-                   int* overflow, int stat_stride, hipStream_t st)
+                   int* overflow, int stat_stride, hipStream_t st, const int* index)
 {
     if (n_img <= 0) return AV_OK;
     if ((int64_t)w * h > (int64_t)(AV_KP_RASTER_MASK + 1)) {
@@ -318,7 +320,7 @@ int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, int bo
     { const char* e = getenv("AV_FAST_DBG"); a.dbg = e ? atoi(e) : 0; }
     static const bool xcd_map = [] { const char* e = getenv("AV_FAST_XCD"); return !(e && atoi(e) == 0); }();      // A/B switch
     const int tx = (w + TW - 1) / TW, ty = (h + TH - 1) / TH;
-    a.n_img = n_img; a.tiles_x = xcd_map ? tx : 0; a.tiles_y = ty;
+    a.n_img = n_img; a.tiles_x = xcd_map ? tx : 0; a.tiles_y = ty; a.index = index;
     dim3 grid = xcd_map ? dim3((unsigned)(tx * ty) * 8u * (unsigned)((n_img + 7) / 8)) : dim3(tx, ty, n_img);
     hipLaunchKernelGGL(fast_kernel, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();

@@ -68,7 +68,13 @@ struct FeDev {
     // output
     long long* out_ids; double* out_uv; int* out_n;
     int* counters;
+    // Shared frame store (av_frontend_frames_*): stream s reads storage entry slot_cur[s] of the FAST lists (and, through the maps
+    // handed to the LK launches, of the images and pyramids); < 0 = the stream has no frame in this step: its workgroups return at
+    // once and its state stays as it is.  Null = every stream owns entry s (av_frontend_step / _step_host).
+    const int* slot_cur;
 };
+
+__device__ __forceinline__ bool fe_idle(const FeDev& d, int s) { return d.slot_cur != nullptr && d.slot_cur[s] < 0; }
 
 __device__ __forceinline__ int cell_of(const FeDev& d, float x, float y)
 {
@@ -133,6 +139,7 @@ __device__ __forceinline__ bool stereo_gate(const FeDev& d, float p0x, float p0y
 __global__ __launch_bounds__(256) void track_prepare_kernel(FeDev d, int par)
 {
     const int s = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (fe_idle(d, s)) return;
     const int n = d.n_feat[par][s];
     if (i == 0) { d.trk_count[s] = n; d.counters[s * NCNT + CNT_BEFORE] = n; }
     if (i >= n) return;
@@ -151,6 +158,7 @@ __global__ __launch_bounds__(256) void track_gate_kernel(FeDev d)
 {
     __shared__ int lds4[4];
     const int s = blockIdx.x;
+    if (fe_idle(d, s)) return;
     const int n = d.trk_count[s];
     int base = 0;
     for (int i0 = 0; i0 < n; i0 += 256) {
@@ -190,6 +198,7 @@ __global__ __launch_bounds__(256) void rebin_kernel(FeDev d, int par)
 {
     __shared__ int lds4[4];
     const int s = blockIdx.x;
+    if (fe_idle(d, s)) return;
     const int n = d.sv_count[s];
     int base = 0;
     for (int i0 = 0; i0 < n; i0 += 256) {
@@ -241,6 +250,8 @@ __global__ __launch_bounds__(256) void select_kernel(FeDev d)
     int* ccnt = off + d.C + 1;   // [C]   FAST keypoints per cell
     int* tpre = ccnt + d.C;      // [n_tiles + 1] prefix of the detector's per-tile counts
     const int s = blockIdx.x;
+    if (fe_idle(d, s)) return;
+    const int ts = d.slot_cur ? d.slot_cur[s] : s;              // storage entry of this frame's FAST lists
     const bool first = d.first_frame[s] != 0;
     // bin the detector's per-tile survivor lists into the per-cell lists (feature_adder.py:66-71: row = y / grid_height,
     // col = x / grid_width).  The cell lists are unordered; everything below orders by (response, raster) key.
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(256) void select_kernel(FeDev d)
         for (int c = threadIdx.x; c < d.C; c += 256) ccnt[c] = 0;
         __syncthreads();
         int mx = 0;
-        for (int t = threadIdx.x; t < nt; t += 256) { const int n = d.tile_count[(size_t)s * nt + t]; tpre[t] = n; mx = max(mx, n); }
+        for (int t = threadIdx.x; t < nt; t += 256) { const int n = d.tile_count[(size_t)ts * nt + t]; tpre[t] = n; mx = max(mx, n); }
         if (mx > 0) atomicMax(&tmax, mx);
         __syncthreads();
         const int maxcount = tmax;
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(256) void select_kernel(FeDev d)
                 for (int u = 0; u < BU; ++u) {
                     const int j = j0 + 256 * u, t = j / BK, k = kb + (j % BK);
                     ok[u] = j < nt * BK && k < tpre[min(t, nt - 1)];
-                    word[u] = ok[u] ? d.tile_kp[((size_t)s * nt + t) * d.tile_cap + k] : 0u;
+                    word[u] = ok[u] ? d.tile_kp[((size_t)ts * nt + t) * d.tile_cap + k] : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < BU; ++u) {
@@ -373,6 +384,7 @@ __global__ __launch_bounds__(256) void cand_round2_kernel(FeDev d)
 {
     __shared__ int r2n;
     const int s = blockIdx.x;
+    if (fe_idle(d, s)) return;
     const int* coff = d.cand_off + s * (d.C + 1);
     const bool first = d.first_frame[s] != 0;
     if (threadIdx.x == 0) r2n = 0;
@@ -433,6 +445,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FeDev d, int par)
     int* flags = ism;                 ism += 4;                      // [0] has_new among published
 
     const int s = blockIdx.x;
+    if (fe_idle(d, s)) { if (threadIdx.x == 0) d.out_n[s] = 0; return; }       // nothing published, grid untouched
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int T = d.cur_count[s];
     const int ncand = d.cand_count[s];
@@ -615,6 +628,22 @@ struct av_frontend {
     // av_frontend_step when the engine was created with AV_FE_INPUTS_PERSIST (include/airvision.h).
     const uint8_t* l0_img[3] = {nullptr, nullptr, nullptr}; int64_t l0_stride[3] = {0, 0, 0};
     void* zero_region = nullptr; size_t zero_bytes = 0;
+    // Shared frame store (av_frontend_frames_reserve / _upload / av_frontend_step_frames): every DISTINCT stereo frame of a sweep is
+    // uploaded, pyramided and FAST-scanned once and stays resident; the streams that replay it -- the offset streams of one
+    // sequence, run.bat:4-12 / dataset.py:206-214 -- only carry an index into the store.
+    struct FrameStore {
+        int n_slots = 0;
+        uint8_t* img = nullptr;                  // [n_slots][2][w * h]: cam0, cam1 (level 0 is read in place)
+        uint8_t* pyr = nullptr;                  // [n_slots][2][lay.bytes]
+        uint32_t* tile_kp = nullptr; int* tile_count = nullptr;      // FAST survivor lists of cam0, per slot
+        bool l0_in_place = true;                 // false if the pyramid launcher had to write padded level-0 copies (unaligned geometry)
+        std::vector<int> prev;                   // host: slot of every stream's previous frame (-1: none yet)
+        struct Up { uint8_t* pin = nullptr; int* idx_h = nullptr; int* idx_d = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
+        Up up[4]; int up_next = 0;               // upload staging ring (pinned frames + the slot list of the upload's kernels)
+        hipEvent_t uploaded = nullptr; bool any_upload = false;      // copy stream: the newest upload's kernels have finished
+        hipEvent_t stepped = nullptr; bool any_step = false;          // step stream: the newest step has finished
+        long long frames_uploaded = 0;
+    } fs;
     std::vector<void*> allocs;
     double* dH = nullptr;
     double* hH[8] = {nullptr}; hipEvent_t hH_ev[8]; int hH_slot = 0;
@@ -700,10 +729,13 @@ struct Span {
     }
 };
 
-int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t img_stride, const double* ts, hipStream_t st, bool inputs_persist)
+// slots != nullptr: the step reads the shared frame store (stream s: entry slots[s], < 0 = no frame in this step); img0 / img1 unused.
+int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t img_stride, const double* ts, hipStream_t st, bool inputs_persist,
+              const int32_t* slots = nullptr)
 {
-    FeDev& d = fe->d;
+    FeDev d = fe->d;                         // by value: the kernels take it by value, the frame-store step patches a few fields
     const int S = d.S;
+    const bool frames = slots != nullptr;
     AV_HIP(hipSetDevice(fe->device));
     // host: IMU rotation prediction -> homographies
     const int slot = fe->hH_slot;
@@ -711,8 +743,17 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
     AV_HIP(hipEventSynchronize(fe->hH_ev[slot]));
     double* hH = fe->hH[slot];
     bool any_first = false;
+    int* hmap = reinterpret_cast<int*>(hH + (size_t)9 * S);      // [2][S] behind the homographies: this frame's / the previous frame's store entry
     for (int s = 0; s < S; ++s) {
         StreamHost& sh = fe->streams[s];
+        if (frames) {
+            hmap[s] = slots[s] < 0 ? -1 : slots[s]; hmap[S + s] = fe->fs.prev[s];
+            if (slots[s] < 0) {                  // no frame for this stream in this step: its IMU buffer, t_prev and grid stay as they are
+                for (int i = 0; i < 9; ++i) hH[s * 9 + i] = (i % 4 == 0) ? 1.0 : 0.0;
+                continue;
+            }
+            fe->fs.prev[s] = slots[s];
+        }
         if (sh.first) {
             any_first = true;
             for (int i = 0; i < 9; ++i) hH[s * 9 + i] = (i % 4 == 0) ? 1.0 : 0.0;
@@ -722,42 +763,58 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
         sh.t_prev = ts[s];
         sh.first = false;
     }
-    AV_HIP(hipMemcpyAsync(fe->dH, hH, sizeof(double) * 9 * S, hipMemcpyHostToDevice, st));
+    AV_HIP(hipMemcpyAsync(fe->dH, hH, sizeof(double) * 9 * S + (frames ? sizeof(int) * 2 * S : 0), hipMemcpyHostToDevice, st));
     AV_HIP(hipEventRecord(fe->hH_ev[slot], st));
     AV_HIP(hipMemsetAsync(fe->zero_region, 0, fe->zero_bytes, st));
+    const int* map_cur = nullptr; const int* map_prev = nullptr;
+    if (frames) {
+        map_cur = reinterpret_cast<const int*>(fe->dH + (size_t)9 * S); map_prev = map_cur + S;
+        d.slot_cur = map_cur; d.tile_kp = fe->fs.tile_kp; d.tile_count = fe->fs.tile_count;
+        if (fe->fs.any_upload) AV_HIP(hipStreamWaitEvent(st, fe->fs.uploaded, 0));      // the frames this step reads are in the store, pyramids and FAST lists with them
+    }
 
     const int par = fe->parity;              // prev grid buffer / prev cam0 pyramid slot
     const int cur0 = par ^ 1;                // curr cam0 pyramid slot (0/1), cam1 pyramid is slot 2
-    const int64_t sstride = 3 * fe->lay.bytes, slotb = fe->lay.bytes;
+    int64_t sstride = 3 * fe->lay.bytes; const int64_t slotb = fe->lay.bytes;
     int rc;
     static const bool zc_off = [] { const char* e = getenv("AV_FE_ZERO_COPY"); return e && atoi(e) == 0; }();      // A/B switch
-    bool wrote_l0 = true;
-    { Span sp(fe, 0, st);
-      if ((rc = av_launch_pyramid(img0, img1, img_stride, S, 2, fe->geom, fe->pyr, sstride, slotb, cur0, 2, st, !(inputs_persist && !zc_off), &wrote_l0))) return rc; }
-    fe->l0_img[cur0] = wrote_l0 ? nullptr : img0; fe->l0_img[2] = wrote_l0 ? nullptr : img1;
-    fe->l0_stride[cur0] = fe->l0_stride[2] = img_stride;
-    const uint8_t* I_prev0 = fe->l0_img[par]; const int64_t st_prev0 = fe->l0_stride[par];      // (first frame: nothing is tracked from it)
-    const uint8_t* I_cur0 = fe->l0_img[cur0]; const uint8_t* I_cur1 = fe->l0_img[2];
-
-    const uint8_t* P_prev0 = fe->pyr + par * slotb;
-    const uint8_t* P_cur0 = fe->pyr + cur0 * slotb;
-    const uint8_t* P_cur1 = fe->pyr + 2 * slotb;
+    const uint8_t *I_prev0, *I_cur0, *I_cur1, *P_prev0, *P_cur0, *P_cur1; int64_t st_prev0;
+    if (frames) {
+        // pyramids and level-0 images of both cameras lie in the store, built when the frame was uploaded: entry e of camera c at
+        // pyr + (2 e + c) * bytes / img + (2 e + c) * w * h; the LK launches index it through map_prev / map_cur
+        const size_t hw = (size_t)d.w * d.h;
+        sstride = 2 * slotb; img_stride = (int64_t)(2 * hw); st_prev0 = img_stride;
+        P_prev0 = P_cur0 = fe->fs.pyr; P_cur1 = fe->fs.pyr + slotb;
+        I_prev0 = I_cur0 = fe->fs.l0_in_place ? fe->fs.img : nullptr; I_cur1 = fe->fs.l0_in_place ? fe->fs.img + hw : nullptr;
+    } else {
+        bool wrote_l0 = true;
+        { Span sp(fe, 0, st);
+          if ((rc = av_launch_pyramid(img0, img1, img_stride, S, 2, fe->geom, fe->pyr, sstride, slotb, cur0, 2, st, !(inputs_persist && !zc_off), &wrote_l0))) return rc; }
+        fe->l0_img[cur0] = wrote_l0 ? nullptr : img0; fe->l0_img[2] = wrote_l0 ? nullptr : img1;
+        fe->l0_stride[cur0] = fe->l0_stride[2] = img_stride;
+        I_prev0 = fe->l0_img[par]; st_prev0 = fe->l0_stride[par];      // (first frame: nothing is tracked from it)
+        I_cur0 = fe->l0_img[cur0]; I_cur1 = fe->l0_img[2];
+        P_prev0 = fe->pyr + par * slotb;
+        P_cur0 = fe->pyr + cur0 * slotb;
+        P_cur1 = fe->pyr + 2 * slotb;
+    }
 
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(track_prepare_kernel, dim3((d.NT + 255) / 256, S), dim3(256), 0, st, d, par);
       AV_LAUNCH_CHECK(); }
     { Span sp(fe, 1, st);
-      if ((rc = av_launch_lk(P_prev0, P_cur0, sstride, S, fe->geom, d.trk_prev, d.trk_next, d.trk_status, d.trk_count, d.NT, d.NT, fe->lk, st, nullptr, I_prev0, st_prev0, I_cur0, img_stride))) return rc; }
+      if ((rc = av_launch_lk(P_prev0, P_cur0, sstride, S, fe->geom, d.trk_prev, d.trk_next, d.trk_status, d.trk_count, d.NT, d.NT, fe->lk, st, nullptr, I_prev0, st_prev0, I_cur0, img_stride, map_prev, map_cur))) return rc; }
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(track_gate_kernel, dim3(S), dim3(256), 0, st, d);
       AV_LAUNCH_CHECK(); }
     { Span sp(fe, 1, st);
-      if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.sv_p0, d.sv_p1, d.sv_st, d.sv_count, d.NT, d.NT, fe->lk, st, nullptr, I_cur0, img_stride, I_cur1, img_stride))) return rc; }
+      if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.sv_p0, d.sv_p1, d.sv_st, d.sv_count, d.NT, d.NT, fe->lk, st, nullptr, I_cur0, img_stride, I_cur1, img_stride, map_cur, map_cur))) return rc; }
     { Span sp(fe, 1, st);
-      if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.sv_p1, d.sv_back, d.sv_st2, d.sv_count, d.NT, d.NT, fe->lk, st, nullptr, I_cur1, img_stride, I_cur0, img_stride))) return rc; }
+      if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.sv_p1, d.sv_back, d.sv_st2, d.sv_count, d.NT, d.NT, fe->lk, st, nullptr, I_cur1, img_stride, I_cur0, img_stride, map_cur, map_cur))) return rc; }
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(rebin_kernel, dim3(S), dim3(256), 0, st, d, par);
       AV_LAUNCH_CHECK(); }
+    if (!frames) {
     Span* fast_span = new Span(fe, 2, st);
     // FAST reads level 0 of the cam0 pyramid built above (same pixels as the input image, with a 16-pixel frame: every
     // tile but the right-most column copies whole dwords without clamping)
@@ -768,29 +825,31 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
                              nullptr, nullptr, 0, d.tile_kp, d.tile_count, d.counters + CNT_OVF, NCNT, st);
     if (rc) { delete fast_span; return rc; }
     delete fast_span;
+    }                                            // (frame store: FAST ran when the frame was uploaded)
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(select_kernel, dim3(S), dim3(256), sizeof(int) * (3 * d.C + 1 + d.n_tiles + 1), st, d);
       AV_LAUNCH_CHECK(); }
     const int r1_launch = any_first ? d.CC : d.C * (d.gmax < CAND_R1 ? d.gmax : CAND_R1);
     { Span sp(fe, 1, st);
-      if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.cand_p0, d.cand_p1, d.cand_st, d.r1_count, d.CC, r1_launch, fe->lk, st, d.r1_list, I_cur0, img_stride, I_cur1, img_stride))) return rc; }
+      if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.cand_p0, d.cand_p1, d.cand_st, d.r1_count, d.CC, r1_launch, fe->lk, st, d.r1_list, I_cur0, img_stride, I_cur1, img_stride, map_cur, map_cur))) return rc; }
     { Span sp(fe, 1, st);
-      if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.r1_count, d.CC, r1_launch, fe->lk, st, d.r1_list, I_cur1, img_stride, I_cur0, img_stride))) return rc; }
+      if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.r1_count, d.CC, r1_launch, fe->lk, st, d.r1_list, I_cur1, img_stride, I_cur0, img_stride, map_cur, map_cur))) return rc; }
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(cand_round2_kernel, dim3(S), dim3(256), 0, st, d);
       AV_LAUNCH_CHECK(); }
     if (d.gmax > CAND_R1) {                       // round 2: the rest of the cells that are still short of inliers (usually none)
         const int r2_launch = d.C * (d.gmax - CAND_R1);
         { Span sp(fe, 1, st);
-          if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.cand_p0, d.cand_p1, d.cand_st, d.r2_count, d.CC, r2_launch, fe->lk, st, d.r2_list, I_cur0, img_stride, I_cur1, img_stride))) return rc; }
+          if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.cand_p0, d.cand_p1, d.cand_st, d.r2_count, d.CC, r2_launch, fe->lk, st, d.r2_list, I_cur0, img_stride, I_cur1, img_stride, map_cur, map_cur))) return rc; }
         { Span sp(fe, 1, st);
-          if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.r2_count, d.CC, r2_launch, fe->lk, st, d.r2_list, I_cur1, img_stride, I_cur0, img_stride))) return rc; }
+          if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.r2_count, d.CC, r2_launch, fe->lk, st, d.r2_list, I_cur1, img_stride, I_cur0, img_stride, map_cur, map_cur))) return rc; }
     }
     size_t fin_lds = sizeof(unsigned long long) * d.NSORT + sizeof(int) * (2 * d.C * d.gmin + 2 * d.C + 3 * (d.C + 1) + 4);
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(finalize_kernel, dim3(S), dim3(256), fin_lds, st, d, par);
       AV_LAUNCH_CHECK(); }
     fe->parity = par ^ 1;
+    if (frames) { AV_HIP(hipEventRecord(fe->fs.stepped, st)); fe->fs.any_step = true; }
     return AV_OK;
 }
 
@@ -850,7 +909,7 @@ AV_EXPORT int av_frontend_create(const av_frontend_config* cfg, int n_streams, i
     }
     A(d.next_id, S)
     if ((rc = dev_alloc(fe, &d.first_frame, (size_t)S, 1))) { av_frontend_destroy(fe); return rc; }   // bytes 0x01 -> non-zero ints
-    A(fe->dH, 9 * S)
+    A(fe->dH, 9 * S + S)                       // + [2][S] ints: the frame-store maps of the step (step_impl)
     d.Hmat = fe->dH;
     A(d.trk_prev, 2 * S * d.NT) A(d.trk_next, 2 * S * d.NT) A(d.trk_status, S * d.NT)
     A(d.sv_src, S * d.NT) A(d.sv_p0, 2 * S * d.NT) A(d.sv_init, 2 * S * d.NT) A(d.sv_p1, 2 * S * d.NT) A(d.sv_st, S * d.NT)
@@ -877,7 +936,7 @@ AV_EXPORT int av_frontend_create(const av_frontend_config* cfg, int n_streams, i
     A(fe->pyr, (size_t)S * 3 * fe->lay.bytes)
 #undef A
     for (int i = 0; i < 8; ++i) {
-        if (hipHostMalloc((void**)&fe->hH[i], sizeof(double) * 9 * S, hipHostMallocDefault) != hipSuccess ||
+        if (hipHostMalloc((void**)&fe->hH[i], sizeof(double) * (9 * S + S), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&fe->hH_ev[i], hipEventDisableTiming) != hipSuccess) {
             av_set_error("av_frontend_create: pinned staging allocation failed");
             av_frontend_destroy(fe);
@@ -914,6 +973,14 @@ AV_EXPORT void av_frontend_destroy(av_frontend* fe)
         if (h.copied) (void)hipEventDestroy(h.copied);
         if (h.consumed) (void)hipEventDestroy(h.consumed);
     }
+    for (av_frontend::FrameStore::Up& u : fe->fs.up) {
+        if (u.pin) (void)hipHostFree(u.pin);
+        if (u.idx_h) (void)hipHostFree(u.idx_h);
+        if (u.idx_d) (void)hipFree(u.idx_d);
+        if (u.done) (void)hipEventDestroy(u.done);
+    }
+    if (fe->fs.uploaded) (void)hipEventDestroy(fe->fs.uploaded);
+    if (fe->fs.stepped) (void)hipEventDestroy(fe->fs.stepped);
     if (fe->copy_stream) (void)hipStreamDestroy(fe->copy_stream);
     for (int i = 0; i < 8; ++i) {
         if (fe->hH[i]) { (void)hipHostFree(fe->hH[i]); (void)hipEventDestroy(fe->hH_ev[i]); }
@@ -999,6 +1066,100 @@ AV_EXPORT int av_frontend_step_host(av_frontend* fe, const uint8_t* img0_host, c
     AV_HIP(hipEventRecord(h.consumed, st));
     h.used = true;
     return AV_OK;
+}
+
+// ---- shared frame store -------------------------------------------------------------------------------------------------
+AV_EXPORT int av_frontend_frames_reserve(av_frontend* fe, int n_slots)
+{
+    if (!fe || n_slots <= 0) { av_set_error("av_frontend_frames_reserve: bad arguments"); return AV_E_INVALID; }
+    av_frontend::FrameStore& fs = fe->fs;
+    if (fs.n_slots) {
+        if (n_slots <= fs.n_slots) return AV_OK;
+        av_set_error("av_frontend_frames_reserve: the store holds %d entries and cannot grow (asked for %d)", fs.n_slots, n_slots);
+        return AV_E_INVALID;
+    }
+    AV_HIP(hipSetDevice(fe->device));
+    const FeDev& d = fe->d;
+    const size_t hw = (size_t)d.w * d.h;
+    int rc;
+    if ((rc = dev_alloc(fe, &fs.img, (size_t)n_slots * 2 * hw)) || (rc = dev_alloc(fe, &fs.pyr, (size_t)n_slots * 2 * fe->lay.bytes)) ||
+        (rc = dev_alloc(fe, &fs.tile_kp, (size_t)n_slots * d.n_tiles * d.tile_cap)) || (rc = dev_alloc(fe, &fs.tile_count, (size_t)n_slots * d.n_tiles))) return rc;
+    AV_HIP(hipEventCreateWithFlags(&fs.uploaded, hipEventDisableTiming));
+    AV_HIP(hipEventCreateWithFlags(&fs.stepped, hipEventDisableTiming));
+    if (!fe->copy_stream) AV_HIP(hipStreamCreateWithFlags(&fe->copy_stream, hipStreamNonBlocking));
+    fs.prev.assign((size_t)d.S, -1);
+    fs.n_slots = n_slots;
+    return AV_OK;
+}
+
+AV_EXPORT int av_frontend_frames_upload(av_frontend* fe, const int32_t* slots, int n, const uint8_t* img0_host, const uint8_t* img1_host,
+                                        int64_t img_stride, void* stream)
+{
+    (void)stream;
+    if (!fe || n < 0 || (n > 0 && (!slots || !img0_host || !img1_host)) || img_stride < (int64_t)fe->d.w * fe->d.h) {
+        av_set_error("av_frontend_frames_upload: bad arguments");
+        return AV_E_INVALID;
+    }
+    av_frontend::FrameStore& fs = fe->fs;
+    if (!fs.n_slots) { av_set_error("av_frontend_frames_upload: no frame store (av_frontend_frames_reserve first)"); return AV_E_INVALID; }
+    if (n == 0) return AV_OK;
+    for (int i = 0; i < n; ++i)
+        if (slots[i] < 0 || slots[i] >= fs.n_slots) { av_set_error("av_frontend_frames_upload: entry %d outside the store (%d entries)", slots[i], fs.n_slots); return AV_E_INVALID; }
+    AV_HIP(hipSetDevice(fe->device));
+    const FeDev& d = fe->d;
+    const size_t hw = (size_t)d.w * d.h;
+    av_frontend::FrameStore::Up& u = fs.up[fs.up_next];
+    fs.up_next = (fs.up_next + 1) % 4;
+    if (u.used) AV_HIP(hipEventSynchronize(u.done));                // the staging area's previous upload has left it
+    if ((size_t)n > u.cap) {
+        if (u.pin) { (void)hipHostFree(u.pin); (void)hipHostFree(u.idx_h); (void)hipFree(u.idx_d); u.pin = nullptr; u.idx_h = nullptr; u.idx_d = nullptr; }
+        const size_t cap = (size_t)n + 16;
+        AV_HIP(hipHostMalloc((void**)&u.pin, cap * 2 * hw, hipHostMallocDefault));
+        AV_HIP(hipHostMalloc((void**)&u.idx_h, cap * sizeof(int), hipHostMallocDefault));
+        AV_HIP(hipMalloc((void**)&u.idx_d, cap * sizeof(int)));
+        if (!u.done) AV_HIP(hipEventCreateWithFlags(&u.done, hipEventDisableTiming));
+        u.cap = cap;
+    }
+#pragma omp parallel for schedule(static) num_threads(n >= 8 ? 8 : 1)
+    for (int i = 0; i < 2 * n; ++i) {
+        const int f = i >> 1, cam = i & 1;
+        memcpy(u.pin + ((size_t)2 * f + cam) * hw, (cam ? img1_host : img0_host) + (size_t)f * img_stride, hw);
+    }
+    for (int i = 0; i < n; ++i) u.idx_h[i] = slots[i];
+    hipStream_t cs = fe->copy_stream;
+    // The entries handed to an upload are free as of the newest ENQUEUED step (the caller's promise): the copies wait for that step
+    // and run beside whatever the caller enqueues next -- upload the frames of step k + 1 before enqueueing step k and the two overlap.
+    if (fs.any_step) AV_HIP(hipStreamWaitEvent(cs, fs.stepped, 0));
+    AV_HIP(hipMemcpyAsync(u.idx_d, u.idx_h, sizeof(int) * n, hipMemcpyHostToDevice, cs));
+    for (int i = 0; i < n;) {                                        // runs of consecutive entries go down in one copy
+        int j = i + 1;
+        while (j < n && slots[j] == slots[j - 1] + 1) ++j;
+        AV_HIP(hipMemcpyAsync(fs.img + (size_t)slots[i] * 2 * hw, u.pin + (size_t)i * 2 * hw, (size_t)(j - i) * 2 * hw, hipMemcpyHostToDevice, cs));
+        i = j;
+    }
+    int rc;
+    bool wrote_l0 = true;
+    if ((rc = av_launch_pyramid(fs.img, fs.img + hw, (int64_t)(2 * hw), n, 2, fe->geom, fs.pyr, 2 * fe->lay.bytes, fe->lay.bytes, 0, 1, cs, false, &wrote_l0, u.idx_d))) return rc;
+    fs.l0_in_place = !wrote_l0;
+    if (fs.l0_in_place) rc = av_launch_fast(fs.img, (int64_t)(2 * hw), d.w, 0, nullptr, 0, n, d.w, d.h, fe->cfg.fast_threshold,
+                                            nullptr, nullptr, 0, fs.tile_kp, fs.tile_count, nullptr, 0, cs, u.idx_d);
+    else rc = av_launch_fast(fs.pyr + fe->geom.off[0] + (size_t)AV_PYR_BORDER * fe->geom.pitch[0] + AV_PYR_BORDER, 2 * fe->lay.bytes, fe->geom.pitch[0], AV_PYR_BORDER,
+                             nullptr, 0, n, d.w, d.h, fe->cfg.fast_threshold, nullptr, nullptr, 0, fs.tile_kp, fs.tile_count, nullptr, 0, cs, u.idx_d);
+    if (rc) return rc;
+    AV_HIP(hipEventRecord(u.done, cs));
+    AV_HIP(hipEventRecord(fs.uploaded, cs));
+    u.used = true; fs.any_upload = true;
+    fs.frames_uploaded += n;
+    return AV_OK;
+}
+
+AV_EXPORT int av_frontend_step_frames(av_frontend* fe, const int32_t* slot_of_stream, const double* timestamps, void* stream)
+{
+    if (!fe || !slot_of_stream || !timestamps) { av_set_error("av_frontend_step_frames: bad arguments"); return AV_E_INVALID; }
+    if (!fe->fs.n_slots) { av_set_error("av_frontend_step_frames: no frame store (av_frontend_frames_reserve first)"); return AV_E_INVALID; }
+    for (int s = 0; s < fe->d.S; ++s)
+        if (slot_of_stream[s] >= fe->fs.n_slots) { av_set_error("av_frontend_step_frames: stream %d: entry %d outside the store (%d entries)", s, slot_of_stream[s], fe->fs.n_slots); return AV_E_INVALID; }
+    return step_impl(fe, nullptr, nullptr, 0, timestamps, (hipStream_t)stream, true, slot_of_stream);
 }
 
 AV_EXPORT int av_frontend_max_features(const av_frontend* fe) { return fe ? fe->d.MAXF : AV_E_INVALID; }

@@ -60,6 +60,10 @@ struct LKArgs {
     // reach over the image border (what the padded level's frame holds).  Levels >= 1 always come from the padded pyramid.
     const uint8_t* imgI; const uint8_t* imgJ;
     int64_t imgI_stride, imgJ_stride;
+    // Optional storage maps (the front-end's shared frame store, frontend.hip): point set s reads the pyramids / level-0 images of
+    // storage entry mapI[s] (I side) and mapJ[s] (J side) instead of entry s; a negative entry = the set has no frame in this step
+    // and tracks nothing.  Null = identity.
+    const int* mapI; const int* mapJ;
 };
 
 // LDS traffic of one wave is ordered by issue; this keeps the compiler from moving a read of the
@@ -263,12 +267,14 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
     if (a.gx > 0) { const int L = blockIdx.x, j = L >> 3; s = (L & 7) + 8 * (j / a.gx); bx = j % a.gx; if (s >= a.n_set) return; }
     else { s = blockIdx.y; bx = blockIdx.x; }
     const int slot = bx * 16 + g;
+    const int sI = a.mapI ? a.mapI[s] : s, sJ = a.mapJ ? a.mapJ[s] : s;      // storage entries of the two images (scalar loads)
+    if (sI < 0 || sJ < 0) return;
     const int n = min(a.count[s], a.cap);
     if (slot >= n) return;                          // uniform per 16-lane group
     const int pidx = a.index ? a.index[(size_t)s * a.cap + slot] : slot;
 
-    const uint8_t* PI = a.pyrI + s * a.stream_stride;
-    const uint8_t* PJ = a.pyrJ + s * a.stream_stride;
+    const uint8_t* PI = a.pyrI + sI * a.stream_stride;
+    const uint8_t* PJ = a.pyrJ + sJ * a.stream_stride;
     const size_t pi = (size_t)s * a.cap + pidx;
     const float prevx0 = a.prev[2 * pi], prevy0 = a.prev[2 * pi + 1];
     float curx = a.next[2 * pi], cury = a.next[2 * pi + 1];
@@ -313,7 +319,7 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
             // source of this level's I rows: the padded pyramid level (origin at row -16, column -16, frame included) or, for
             // level 0 in place, the caller's image (origin at pixel (0, 0), no frame: windows over the border take the slow path)
             const bool extI = level == 0 && a.imgI != nullptr;                      // wave-uniform
-            const uint8_t* L0 = extI ? a.imgI + (size_t)s * (size_t)a.imgI_stride : PI + a.g.off[level];
+            const uint8_t* L0 = extI ? a.imgI + (size_t)sI * (size_t)a.imgI_stride : PI + a.g.off[level];
             const int pI = extI ? w : pitch, bI = extI ? 0 : AV_PYR_BORDER;
             const bool act = dwl < 5;                                    // 5 of the 8 slots of a row carry a dword
             if (!extI || (ipx >= 1 && ipx + 16 < w && ipy >= 1 && ipy + 16 < h)) {
@@ -454,7 +460,7 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
                 wave_lds_sync();
                 {
                     const bool extJ = level == 0 && a.imgJ != nullptr;              // wave-uniform
-                    const uint8_t* LJ0 = extJ ? a.imgJ + (size_t)s * (size_t)a.imgJ_stride : PJ + a.g.off[level];
+                    const uint8_t* LJ0 = extJ ? a.imgJ + (size_t)sJ * (size_t)a.imgJ_stride : PJ + a.g.off[level];
                     const int pJ = extJ ? w : pitch, bJ = extJ ? 0 : AV_PYR_BORDER;
                     if (!extJ || (X0 >= 0 && X0 + TILE_COLS <= w && Y0 >= 0 && Y0 + TILE_ROWS <= h)) {
                         const uint32_t joff = (uint32_t)(__mul24(Y0 + sub + bJ, pJ) + X0 + bJ + 4 * dwl);
@@ -557,6 +563,8 @@ __global__ __launch_bounds__(256) void lk_track_generic_kernel(LKArgs a, int WIN
     constexpr int W_BITS = 14;
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.y, slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int sI = a.mapI ? a.mapI[s] : s, sJ = a.mapJ ? a.mapJ[s] : s;
+    if (sI < 0 || sJ < 0) return;
     const int n = min(a.count[s], a.cap);
     if (slot >= n) return;                                   // wave-uniform
     const int pidx = a.index ? a.index[(size_t)s * a.cap + slot] : slot;
@@ -573,9 +581,9 @@ __global__ __launch_bounds__(256) void lk_track_generic_kernel(LKArgs a, int WIN
         {
             const bool extI = level == 0 && a.imgI != nullptr, extJ = level == 0 && a.imgJ != nullptr;
             const int pitch = a.g.pitch[level];
-            LI.base = extI ? a.imgI + (size_t)s * (size_t)a.imgI_stride : a.pyrI + s * a.stream_stride + a.g.off[level] + (size_t)AV_PYR_BORDER * pitch + AV_PYR_BORDER;
+            LI.base = extI ? a.imgI + (size_t)sI * (size_t)a.imgI_stride : a.pyrI + sI * a.stream_stride + a.g.off[level] + (size_t)AV_PYR_BORDER * pitch + AV_PYR_BORDER;
             LI.pitch = extI ? w : pitch; LI.w = w; LI.h = h;
-            LJ.base = extJ ? a.imgJ + (size_t)s * (size_t)a.imgJ_stride : a.pyrJ + s * a.stream_stride + a.g.off[level] + (size_t)AV_PYR_BORDER * pitch + AV_PYR_BORDER;
+            LJ.base = extJ ? a.imgJ + (size_t)sJ * (size_t)a.imgJ_stride : a.pyrJ + sJ * a.stream_stride + a.g.off[level] + (size_t)AV_PYR_BORDER * pitch + AV_PYR_BORDER;
             LJ.pitch = extJ ? w : pitch; LJ.w = w; LJ.h = h;
         }
         const float scale = (float)(1. / (1 << level));
@@ -691,7 +699,7 @@ __global__ __launch_bounds__(256) void lk_track_generic_kernel(LKArgs a, int WIN
 int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride, int n_set, const PyrGeom& g,
                  const float* prev, float* next, uint8_t* status, const int* count, int cap, int launch_pts,
                  const LKParams& p, hipStream_t st, const int* index,
-                 const uint8_t* imgI, int64_t imgI_stride, const uint8_t* imgJ, int64_t imgJ_stride)
+                 const uint8_t* imgI, int64_t imgI_stride, const uint8_t* imgJ, int64_t imgJ_stride, const int* mapI, const int* mapJ)
 {
     if (n_set <= 0 || launch_pts <= 0) return AV_OK;
     if (p.win < 3 || p.win > LKG_MAX_WIN) { av_set_error("av_lk_track: winSize %d outside 3 .. %d", p.win, LKG_MAX_WIN); return AV_E_INVALID; }
@@ -704,7 +712,7 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
         if (a.g.w[l] <= p.win || a.g.h[l] <= p.win) { a.g.levels = l; break; }
     a.prev = prev; a.next = next; a.status = status; a.count = count; a.index = index; a.cap = cap;
     a.max_iter = p.max_iter; a.eps2 = p.eps2; a.min_eig = p.min_eig;
-    a.imgI = imgI; a.imgJ = imgJ; a.imgI_stride = imgI_stride; a.imgJ_stride = imgJ_stride;
+    a.imgI = imgI; a.imgJ = imgJ; a.imgI_stride = imgI_stride; a.imgJ_stride = imgJ_stride; a.mapI = mapI; a.mapJ = mapJ;
     if (launch_pts > cap) launch_pts = cap;
     if (p.win != 15) {           // any other window of config.win_size: the general kernel (one wavefront per point)
         a.n_set = n_set; a.gx = 0;

@@ -29,11 +29,20 @@ struct PyrArgs {
     int slot0, slot1;
     PyrGeom g;
     int n_img, tiles_x, tiles_y;       // pyr_l0l1_kernel: XCD-aware 1-D launch when tiles_x > 0
+    const int* index;                  // optional: image group i (a "stream") is storage entry index[i] of img0 / img1 / pyr_base (shared frame store)
 };
+
+// image number of the launch -> (storage entry, camera)
+__device__ __forceinline__ void pyr_entry(const PyrArgs& a, int img, int& s, int& cam)
+{
+    s = img / a.imgs_per_stream; cam = img - s * a.imgs_per_stream;
+    if (a.index) s = a.index[s];
+}
 
 __device__ __forceinline__ uint8_t* pyr_of(const PyrArgs& a, int img)
 {
-    int s = img / a.imgs_per_stream, cam = img - s * a.imgs_per_stream;
+    int s, cam;
+    pyr_entry(a, img, s, cam);
     return a.pyr_base + s * a.stream_stride + (cam == 0 ? a.slot0 : a.slot1) * a.slot_stride;
 }
 
@@ -48,7 +57,8 @@ __global__ __launch_bounds__(256) void pad_level0_kernel(PyrArgs a)
     if (q >= chunks_per_row * ph) return;
     int yp = q / chunks_per_row, xc = q - yp * chunks_per_row;
     int img = blockIdx.y;
-    int s = img / a.imgs_per_stream, cam = img - s * a.imgs_per_stream;
+    int s, cam;
+    pyr_entry(a, img, s, cam);
     const uint8_t* src = (cam == 0 ? a.img0 : a.img1) + s * a.img_stride;
     uint8_t* dst = pyr_of(a, img) + a.g.off[0];
     int y = av_reflect101(yp - AV_PYR_BORDER, h);
@@ -102,7 +112,8 @@ __global__ __launch_bounds__(256) void pyr_l0l1_kernel(PyrArgs a)
         by = t / a.tiles_x; bx = t - by * a.tiles_x;
     } else { img = blockIdx.z; bx = blockIdx.x; by = blockIdx.y; }
     const int x0 = bx * FT_W, y0 = by * FT_H;
-    const int s = img / a.imgs_per_stream, cam = img - s * a.imgs_per_stream;
+    int s, cam;
+    pyr_entry(a, img, s, cam);
     const uint8_t* in = (cam == 0 ? a.img0 : a.img1) + s * a.img_stride;
     uint8_t* base = pyr_of(a, img);
     uint8_t* d0 = base + a.g.off[0];
@@ -432,7 +443,7 @@ PyrGeom av_make_geom(const av_pyr_layout& l)
 
 int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stride, int n_streams, int imgs_per_stream,
                       const PyrGeom& g, uint8_t* pyr_base, int64_t stream_stride, int64_t slot_stride, int slot0, int slot1,
-                      hipStream_t st, bool write_level0, bool* wrote_level0)
+                      hipStream_t st, bool write_level0, bool* wrote_level0, const int* index)
 {
     if (wrote_level0) *wrote_level0 = true;
     if (n_streams <= 0) return AV_OK;
@@ -440,7 +451,7 @@ int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stri
     a.img0 = img0; a.img1 = img1; a.img_stride = img_stride; a.imgs_per_stream = imgs_per_stream;
     a.pyr_base = pyr_base; a.stream_stride = stream_stride; a.slot_stride = slot_stride;
     a.slot0 = slot0; a.slot1 = slot1; a.g = g;
-    a.n_img = 0; a.tiles_x = 0; a.tiles_y = 0;
+    a.n_img = 0; a.tiles_x = 0; a.tiles_y = 0; a.index = index;
     const int n_img = n_streams * imgs_per_stream;
     const int w = g.w[0], h = g.h[0];
     // the fused level-0 + level-1 kernel needs: dword-aligned rows, whole 32-row tiles, a last tile column that still holds the

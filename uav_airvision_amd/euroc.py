@@ -184,6 +184,104 @@ class FrameStager(object):
         self.pool.shutdown(wait=True)
 
 
+class SharedFramePlan(object):
+    """Which DISTINCT frames a batch of streams reads at which step, and where each lives in the front-end's device frame store
+    (`FrontendEngine.frames_*`).  The reference's sweep replays one sequence from several start offsets (run.bat:4-12; an offset
+    only moves the start index, dataset.py:206-214): stream i reads frame start_i + k at step k, so every frame is read by every
+    offset stream a few steps apart -- here it is decoded, uploaded, pyramided and FAST-scanned once, when the first of them
+    reaches it, and dropped when the last has tracked away from it.  Streams of different sequences simply share nothing.
+
+    Frames are keyed by their (cam0 path, cam1 path).  Computed up front from the datasets' file lists:
+      n_steps, n_slots            steps of the longest stream; store entries needed (the most frames ever live at once)
+      slots[k]    int32[S]        store entry stream s reads at step k; -1 = the stream is over
+      ts[k]       float64[S]      frame time; -1 = over
+      new[k]      [(entry, cam0 path, cam1 path)]   frames first read at step k: upload them before the step (at the earliest
+                                  right before step k - 1 is enqueued: an entry is handed out again only two steps after its last reader)
+    A frame is read as the current image at step k and as the previous image at step k + 1 of the same stream."""
+
+    def __init__(self, datasets, max_frames=None):
+        files = []
+        for d in datasets:
+            f = list(d.stereo_files)
+            files.append(f if max_frames is None else f[:max_frames])
+        S = self.S = len(files)
+        self.n_steps = max([len(f) for f in files] + [0])
+        last_need = {}
+        for f in files:
+            for k, (_t, p0, p1) in enumerate(f):
+                need = k + 1 if k + 1 < len(f) else k
+                key = (p0, p1)
+                if last_need.get(key, -1) < need:
+                    last_need[key] = need
+        self.slots = np.full((self.n_steps, S), -1, np.int32)
+        self.ts = np.full((self.n_steps, S), -1.0)
+        self.new = [[] for _ in range(self.n_steps)]
+        import heapq
+        free, where, n_slots = [], {}, 0             # free: heap of (first step the entry may be rewritten for, entry)
+        for k in range(self.n_steps):
+            for s, f in enumerate(files):
+                if k >= len(f):
+                    continue
+                t, p0, p1 = f[k]
+                key = (p0, p1)
+                e = where.get(key)
+                if e is None:
+                    if free and free[0][0] <= k:
+                        e = heapq.heappop(free)[1]
+                    else:
+                        e = n_slots; n_slots += 1
+                    where[key] = e
+                    self.new[k].append((e, p0, p1))
+                self.slots[k, s] = e
+                self.ts[k, s] = t
+            for key in [key for key, e in where.items() if last_need[key] == k]:
+                heapq.heappush(free, (k + 2, where.pop(key)))
+        self.n_slots = max(n_slots, 1)
+        self.n_frames_distinct = sum(len(n) for n in self.new)
+        self.n_stream_frames = int((self.slots >= 0).sum())
+
+
+class SharedFrameStager(object):
+    """Decodes the NEW frames of every step of a `SharedFramePlan` on host threads, a few steps ahead of the GPU (reference: the
+    reader threads of streaming/dataset.py:93-158).  `get(k)` -> (entries int32[n], img0 uint8[n,h,w], img1) of step k; steps must be
+    asked for in order."""
+
+    def __init__(self, plan, height, width, threads=16, ahead=3):
+        from concurrent.futures import ThreadPoolExecutor
+        self.plan, self.h, self.w, self.threads, self.ahead = plan, height, width, threads, ahead
+        self.pool = ThreadPoolExecutor(1)
+        self.futs = {}
+        self.submitted = 0
+        self._fill(0)
+
+    def _decode(self, k):
+        new = self.plan.new[k]
+        n = len(new)
+        buf = np.empty((2 * n, self.h, self.w), np.uint8)
+        if n:
+            decode_batch([e[1] for e in new] + [e[2] for e in new], buf, self.threads)
+        return np.array([e[0] for e in new], np.int32), buf[:n], buf[n:]
+
+    def _fill(self, k):
+        while self.submitted < min(self.plan.n_steps, k + 1 + self.ahead):
+            self.futs[self.submitted] = self.pool.submit(self._decode, self.submitted)
+            self.submitted += 1
+
+    def get(self, k):
+        self._fill(k)
+        res = self.futs.pop(k).result()
+        self._fill(k + 1)
+        return res
+
+    def close(self):
+        for f in self.futs.values():
+            try:
+                f.result()
+            except Exception:
+                pass
+        self.pool.shutdown(wait=True)
+
+
 def replay(dataset, imu_sinks, on_stereo, max_frames=None):
     """Deterministic replay: for each stereo frame at time t deliver every IMU message with
     timestamp <= t to each sink (order of vio.py:43-44), then call on_stereo(msg)."""

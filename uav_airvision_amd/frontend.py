@@ -132,6 +132,33 @@ class FrontendEngine(object):
             N.check(N.lib().av_frontend_step_host(self._h, a0.ctypes.data_as(C.c_void_p), a1.ctypes.data_as(C.c_void_p),
                                                   self.height * self.width, ts, self._stream()))
 
+    def frames_reserve(self, n_slots):
+        """Allocate the shared frame store (av_frontend_frames_reserve): `n_slots` resident stereo frames."""
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_frontend_frames_reserve(self._h, int(n_slots)))
+
+    def frames_upload(self, slots, img0, img1):
+        """Put host frames into the store: slots int32[n], img0 / img1 uint8[n,h,w] (C-contiguous).  Copy, pyramids and FAST of
+        every frame happen once, here, on the engine's copy stream; the arrays are free again on return."""
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        n = len(sl)
+        if n == 0:
+            return
+        a0 = np.ascontiguousarray(img0, dtype=np.uint8).reshape(n, self.height, self.width)
+        a1 = np.ascontiguousarray(img1, dtype=np.uint8).reshape(n, self.height, self.width)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_frontend_frames_upload(self._h, sl.ctypes.data_as(C.c_void_p), n, a0.ctypes.data_as(C.c_void_p),
+                                                      a1.ctypes.data_as(C.c_void_p), self.height * self.width, self._stream()))
+
+    def step_frames(self, slot_of_stream, timestamps):
+        """One step with stream s reading store entry slot_of_stream[s]; < 0 = no frame for that stream in this step."""
+        S = self.n_streams
+        sl = np.ascontiguousarray(slot_of_stream, dtype=np.int32)
+        assert sl.shape == (S,)
+        ts = (C.c_double * S)(*[float(t) for t in np.atleast_1d(timestamps)])
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_frontend_step_frames(self._h, sl.ctypes.data_as(C.c_void_p), ts, self._stream()))
+
     def read_features(self):
         """Synchronises; returns [(ids int64[n], uv float64[n,4])] per stream (u0, v0, u1, v1)."""
         with torch.cuda.device(self.device):

@@ -42,6 +42,14 @@ def broadcast_object(obj, src=0):
     return pickle.loads(buf.cpu().numpy().tobytes())
 
 
+def gather_objects(obj):
+    """Small picklable per-rank results (reports, counters) to EVERY rank, in rank order: world broadcasts of a few hundred bytes at
+    the end of a run."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [obj]
+    return [broadcast_object(obj if dist.get_rank() == r else None, src=r) for r in range(dist.get_world_size())]
+
+
 def max_over_ranks(value):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
