@@ -117,6 +117,28 @@ def test_lk_small_images_bit_exact(ops, w, h, win, max_level):
     assert np.array_equal(p_gpu.view(np.uint32), p_cpu.view(np.uint32)), np.abs(p_gpu - p_cpu).max()
 
 
+@pytest.mark.parametrize('eps,min_eig', [(0.0, 1e-4), (1e-20, 1e-4), (0.003, 1e-4), (0.05, 3e-3), (0.3, 0.02), (10.0, 1e-4)])
+def test_lk_termination_tests_in_float_match_the_fp64_forms(ops, frames0, eps, min_eig):
+    """The 16-lane kernel takes OpenCV's fp64 tests (`delta.ddot(delta) <= eps^2`, `minEig < minEigThreshold`, the 0.01 oscillation
+    stop) in float where float decides the same way (lk.hip: eps_lo / eps_hi / min_eig_up) and in fp64 next to the threshold.
+    eps = 0 and 1e-20 send EVERY step test down the fp64 branch (the float sum can underflow), the others down the float one;
+    the minEig thresholds cut the point set in different places.  All against the oracle's fp64 forms, bit for bit."""
+    from oracle import cvops
+    rng = np.random.default_rng(int(eps * 1000) + 17)
+    xs, ys, _ = cvops.fast_detect(frames0[0].cam0_image, 15)
+    sel = np.linspace(0, len(xs) - 1, 500).astype(int)
+    prev = np.concatenate([np.stack([xs[sel], ys[sel]], 1).astype(np.float32) + np.float32(0.25),
+                           np.stack([rng.uniform(0, 752, 200), rng.uniform(0, 480, 200)], 1).astype(np.float32)])   # incl. weak texture
+    init = prev + rng.normal(0, 2, prev.shape).astype(np.float32)
+    kw = dict(winSize=(15, 15), maxLevel=3, criteria=(3, 30, eps), flags=4, minEigThreshold=min_eig)
+    for I, J in ((frames0[0].cam0_image, frames0[1].cam0_image), (frames0[2].cam0_image, frames0[2].cam1_image)):
+        p_gpu, s_gpu, _ = ops.calc_optical_flow_pyr_lk(I, J, prev, init, **kw)
+        p_cpu, s_cpu, _ = cvops.calc_optical_flow_pyr_lk(I, J, prev, init, **kw)
+        assert np.array_equal(s_gpu, s_cpu), (eps, min_eig, int((s_gpu != s_cpu).sum()))
+        assert 100 < s_cpu.sum() <= len(prev)
+        assert np.array_equal(p_gpu.view(np.uint32), p_cpu.view(np.uint32)), (eps, min_eig, np.abs(p_gpu - p_cpu).max())
+
+
 def test_lk_flat_image_fails_min_eig(ops, cfg):
     I = np.full((480, 752), 90, np.uint8)
     prev = np.array([[100.5, 100.25], [300, 200]], np.float32)

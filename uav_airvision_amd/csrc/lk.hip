@@ -35,6 +35,8 @@
 //     to the scalar CPU oracle.
 // Bound: VALU issue (PMC: ~1,400 VALU instructions per point pass; the staged tiles come from
 // L2/MALL: the padded pyramids of a stream are ~560 KB); HBM sees each pyramid once per frame.
+#include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "av_common.h"
@@ -53,7 +55,11 @@ struct LKArgs {
     const int* index;           // optional [n_set][cap]: point j of set s is index[s*cap + j] (a subset of the point arrays)
     int cap;
     int max_iter;
-    double eps2, min_eig;
+    double eps2;
+    // float forms of the two fp64 thresholds (av_launch_lk): minEig < min_eig (double) <=> minEig < min_eig_up, the smallest float
+    // >= min_eig; the step-length test is decided in float outside (eps_lo, eps_hi) = eps2 (1 -+ 2^-18) and in fp64 inside
+    float min_eig_up, eps_lo, eps_hi;
+    double min_eig;             // the general kernel's fp64 form
     int n_set, gx;              // XCD-aware 1-D launch (gx > 0): gx workgroups per point set, see lk_track_g16_body
     // Level 0 straight from the caller's image (w x h, tightly packed rows) instead of a padded copy in the pyramid: non-null =
     // the I (resp. J) side reads level 0 at img + set * img_stride, with BORDER_REFLECT_101 indexing for the few windows that
@@ -64,7 +70,12 @@ struct LKArgs {
     // storage entry mapI[s] (I side) and mapJ[s] (J side) instead of entry s; a negative entry = the set has no frame in this step
     // and tracks nothing.  Null = identity.
     const int* mapI; const int* mapJ;
+    // diagnostic (AV_LK_PROF=1, lk_track_g16_prof_kernel): per-phase s_memtime sums over every wavefront of the launch
+    unsigned long long* prof;
 };
+
+// phases of a wavefront's life in the 16-lane kernel, as the stamps cut it
+enum { LKP_HEAD = 0, LKP_ISTAGE, LKP_SETUP, LKP_JSTAGE, LKP_ITER, LKP_N, LKP_WAVES = LKP_N, LKP_ITERS, LKP_RESTAGES, LKP_LEVELS, LKP_SLOTS };
 
 // LDS traffic of one wave is ordered by issue; this keeps the compiler from moving a read of the
 // staged tile above the (other lanes') writes that fill it.
@@ -114,8 +125,12 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __bu
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(av_v2u, a) - __builtin_bit_cast(av_v2u, b)); }
 __device__ __forceinline__ uint32_t pk_mul(uint32_t a, unsigned short k) { av_v2u kk = {k, k}; return __builtin_bit_cast(uint32_t, __builtin_bit_cast(av_v2u, a) * kk); }
 
-// exact sum over the 16 lanes of a DPP row of an int32 that may overflow when summed: 16-bit halves
-__device__ __forceinline__ double row_sum16_exact(int v)
+// exact sum S over the 16 lanes of a DPP row of an int32 that may overflow when summed (16-bit halves), returned as
+// (float)(S * 2^-20) rounded ONCE -- the value of (float)((double)S * 2^-20), without the fp64 instructions: the two half sums are
+// exact as floats (|hi| < 2^17, lo < 2^18), so is lo * 2^-20, and the fused multiply-add rounds the exact hi * 2^-4 + lo * 2^-20 =
+// S * 2^-20 once.  (fp64 form: 2 x v_cvt_f64_i32, v_ldexp_f64, v_add_f64, v_ldexp_f64, v_cvt_f32_f64 per sum, 4-16 issue cycles
+// each against 2 -- profiles/r05/valu_issue_microbench.json; five sums per Newton iteration and level set-up.)
+__device__ __forceinline__ float row_sum16_scaled(int v)
 {
     // |v| <= 15 * 8160 * 4080 < 2^29: the sum over a quad still fits int32, the sum over 16 lanes does not
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
@@ -125,7 +140,7 @@ __device__ __forceinline__ double row_sum16_exact(int v)
     hi += __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false);
     lo += __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, false); // row_mirror
     hi += __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, false);
-    return (double)hi * 65536.0 + (double)lo;
+    return __builtin_fmaf((float)hi, 0x1p-4f, (float)lo * 0x1p-20f);
 }
 
 // Bilinear sample of five packed pixel (or derivative) pairs x_i = (v[c], v[c+1]) of this lane's row with the same
@@ -249,12 +264,17 @@ __device__ __forceinline__ void jdiff5(uint32_t T0, uint32_t T1, uint32_t T2, ui
 #undef AV_SL
 }
 
-template <int WIN, int OCC>
+template <int WIN, int OCC, bool PROF = false>
 __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
 {
     static_assert(WIN == 15, "lane map is built for the reference's 15x15 window");
     constexpr int W_BITS = 14;
     __shared__ uint32_t tile_all[16][TILE_DWORDS];
+    // phase stamps (PROF only): cycles since the previous stamp are booked on the phase that just ended
+    unsigned pt[LKP_N] = {0, 0, 0, 0, 0}, plast = 0;             // 32-bit: a wavefront lives ~10^5 cycles
+    unsigned pn_iter = 0, pn_restage = 0, pn_level = 0;
+    if (PROF) plast = (unsigned)__builtin_readcyclecounter();
+#define LK_STAMP(ph) do { if (PROF) { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); pt[ph] += t_ - plast; plast = t_; } } while (0)
     const int g = threadIdx.x >> 4;                 // point slot of this 16-lane group inside the workgroup
     const int r = threadIdx.x & 15;                 // window row owned by this lane (row 15 only feeds row 14)
     uint32_t* tile = tile_all[g];
@@ -281,14 +301,13 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
     const float halfWin = (WIN - 1) * 0.5f;
     const bool rowact = r < WIN;
     bool ok = true;
-    const double FLT_SCALE_D = 1.0 / (1 << 20);
     // byte-pair selectors of v_perm: (byte o, byte o+1) zero-extended into the two 16-bit halves; o+1 == 4 = byte 0 of the next dword
     const uint32_t sel0 = 0x0C010C00u, sel1 = 0x0C020C01u, sel2 = 0x0C030C02u, sel3 = 0x0C040C03u;
 
     for (int level = a.g.levels - 1; level >= 0; --level) {
         const int w = a.g.w[level], h = a.g.h[level], pitch = a.g.pitch[level];
         const int col_lo = -AV_PYR_BORDER, col_hi = pitch - AV_PYR_BORDER;
-        const float scale = (float)(1. / (1 << level));
+        const float scale = __int_as_float((127 - level) << 23);       // 2^-level (written as 1. / (1 << level) it is an fp64 division per level)
         float pvx = prevx0 * scale, pvy = prevy0 * scale;
         if (level == a.g.levels - 1) { curx = curx * scale; cury = cury * scale; }
         else                         { curx = curx * 2.f;   cury = cury * 2.f; }
@@ -313,6 +332,8 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
         // per-lane base plus an immediate -- no per-load index arithmetic on the vector unit.
         const int sub = r >> 3, dwl = r & 7;
         const uint32_t tofs = (uint32_t)(sub * (TPITCH / 4) + dwl);
+        LK_STAMP(LKP_HEAD);
+        if (PROF) ++pn_level;
         wave_lds_sync();
         typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
         {
@@ -348,6 +369,7 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
             }
         }
         wave_lds_sync();
+        LK_STAMP(LKP_ISTAGE);
 
         // ---- this lane's row of the I patch and of the Scharr patches: staged rows r..r+2, 18 bytes of each -------------
         int iv[WIN];
@@ -432,12 +454,12 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
             }
             if (!rowact) { a11 = 0; a12 = 0; a22 = 0; }
         }
-        const float A11 = (float)(row_sum16_exact(a11) * FLT_SCALE_D);
-        const float A12 = (float)(row_sum16_exact(a12) * FLT_SCALE_D);
-        const float A22 = (float)(row_sum16_exact(a22) * FLT_SCALE_D);
+        const float A11 = row_sum16_scaled(a11);
+        const float A12 = row_sum16_scaled(a12);
+        const float A22 = row_sum16_scaled(a22);
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
-        if ((double)minEig < a.min_eig || D < 1.1920928955078125e-7f) {
+        if (minEig < a.min_eig_up || D < 1.1920928955078125e-7f) {
             if (level == 0) ok = false;
             continue;
         }
@@ -447,7 +469,9 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
         float pdx = 0.f, pdy = 0.f;
         int X0 = 0, Y0 = 0;
         bool staged = false;
+        LK_STAMP(LKP_SETUP);
         for (int j = 0; j < a.max_iter; ++j) {
+            if (PROF) ++pn_iter;
             const int inx = (int)floorf(wx), iny = (int)floorf(wy);
             if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) {
                 if (level == 0) ok = false;
@@ -457,6 +481,8 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
             if (!staged || (unsigned)dx0 > (unsigned)(TILE_COLS - 17) || (unsigned)dy0 > (unsigned)(TILE_ROWS - 16)) {
                 X0 = min(max((inx - 6) & ~3, col_lo), col_hi - TILE_COLS);
                 Y0 = min(max(iny - 4, -AV_PYR_BORDER), h + AV_PYR_BORDER - TILE_ROWS);
+                LK_STAMP(LKP_ITER);
+                if (PROF) ++pn_restage;
                 wave_lds_sync();
                 {
                     const bool extJ = level == 0 && a.imgJ != nullptr;              // wave-uniform
@@ -482,6 +508,7 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
                     }
                 }
                 wave_lds_sync();
+                LK_STAMP(LKP_JSTAGE);
                 staged = true;
                 dx0 = inx - X0; dy0 = iny - Y0;
             }
@@ -509,25 +536,54 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
                 b2 = mad16<0, 1>((uint32_t)df[c], ixy[c], b2);
             }
             if (!rowact) { b1 = 0; b2 = 0; }
-            const float fb1 = (float)(row_sum16_exact(b1) * FLT_SCALE_D);
-            const float fb2 = (float)(row_sum16_exact(b2) * FLT_SCALE_D);
+            const float fb1 = row_sum16_scaled(b1);
+            const float fb2 = row_sum16_scaled(b2);
             const float dx = (A12 * fb2 - A22 * fb1) * D;
             const float dy = (A12 * fb1 - A11 * fb2) * D;
             wx += dx; wy += dy;
             curx = wx + halfWin; cury = wy + halfWin;
-            if ((double)dx * dx + (double)dy * dy <= a.eps2) break;
-            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+            // delta.ddot(delta) <= eps^2 is an fp64 test in OpenCV.  e32 lies within 2^-22 (relative) of the exact dx^2 + dy^2, so outside
+            // (eps_lo, eps_hi) the float compare decides the same way; inside (once in ~10^5 iterations) the fp64 form does.
+            const float e32 = __builtin_fmaf(dx, dx, dy * dy);
+            bool conv = e32 <= a.eps_lo;
+            if (__builtin_amdgcn_ballot_w64(e32 > a.eps_lo && e32 < a.eps_hi) != 0) {
+                asm volatile("; fp64 step test");          // keeps the block a branch (if-converted, its fp64 instructions ran every iteration)
+                conv = (double)dx * dx + (double)dy * dy <= a.eps2;
+            }
+            if (conv) break;
+            // |x| < 0.01 (double) for a float x <=> |x| <= 0.01f: 0.01f = 0.00999999977... < 0.01 < the next float up
+            if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
                 curx -= dx * 0.5f; cury -= dy * 0.5f;
                 break;
             }
             pdx = dx; pdy = dy;
         }
+        LK_STAMP(LKP_ITER);
     }
     if (r == 0) {
         a.next[2 * pi] = curx;
         a.next[2 * pi + 1] = cury;
         a.status[pi] = ok ? 1 : 0;
     }
+    if (PROF) {
+        LK_STAMP(LKP_HEAD);
+        // one record per wavefront: its first lane books the wave's clock; iteration / level counts are the maxima over its points
+        // (what the wave executed); every point leader books its own counts for the per-point means
+        unsigned wi = pn_iter, wr = pn_restage, wl = pn_level;
+#pragma unroll
+        for (int d = 16; d < 64; d <<= 1) { wi = max(wi, (unsigned)__shfl_xor((int)wi, d, 64)); wr = max(wr, (unsigned)__shfl_xor((int)wr, d, 64)); wl = max(wl, (unsigned)__shfl_xor((int)wl, d, 64)); }
+        // (every wavefront stamps; one workgroup in 61 books: 10^7 same-address atomics per launch made the profiled kernel 9x slower)
+        const bool book = blockIdx.x % 61 == 0;
+        if (book && (threadIdx.x & 63) == 0) {
+            for (int k = 0; k < LKP_N; ++k) atomicAdd(a.prof + k, (unsigned long long)pt[k]);
+            atomicAdd(a.prof + LKP_WAVES, 1ull);
+            atomicAdd(a.prof + LKP_ITERS, (unsigned long long)wi);
+            atomicAdd(a.prof + LKP_RESTAGES, (unsigned long long)wr);
+            atomicAdd(a.prof + LKP_LEVELS, (unsigned long long)wl);
+        }
+        if (book && r == 0) { atomicAdd(a.prof + LKP_SLOTS, 1ull); atomicAdd(a.prof + LKP_SLOTS + 1, (unsigned long long)pn_iter); atomicAdd(a.prof + LKP_SLOTS + 2, (unsigned long long)pn_restage); }
+    }
+#undef LK_STAMP
 }
 
 // 96 VGPRs: 5 waves per SIMD without spills (the kernel is VALU-issue bound: 4 -> 5 waves bought 1 %, a 6-wave build with
@@ -536,6 +592,26 @@ template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_kernel
 // A/B (AV_LK_WAVES=4): the same body held to four waves per SIMD -- 128 of a SIMD's 512 VGPR rows stay free, room for one wave of
 // the filter's fp64 kernels (64-128 VGPRs) beside four LK waves; with five LK waves (480 rows) no filter wave fits until one retires.
 template <int WIN> __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(256) void lk_track_g16_kernel_w4(LKArgs a) { lk_track_g16_body<WIN, 4>(a); }
+// AV_LK_PROF=1: the same body with s_memtime stamps at the phase boundaries (I staging / patch set-up / J staging / Newton
+// iterations), summed over the wavefronts of every launch and printed at exit (profiles/r05/lk_phase_stamps.txt).
+template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_prof_kernel(LKArgs a) { lk_track_g16_body<WIN, 5, true>(a); }
+
+static unsigned long long* g_lk_prof = nullptr;
+static void lk_prof_report()
+{
+    if (!g_lk_prof) return;
+    unsigned long long h[LKP_SLOTS + 3];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, g_lk_prof, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+    static const char* names[LKP_N] = {"head+tail", "I staging", "set-up", "J staging", "iterations"};
+    double tot = 0;
+    for (int k = 0; k < LKP_N; ++k) tot += (double)h[k];
+    const double nw = (double)h[LKP_WAVES];
+    fprintf(stderr, "AV_LK_PROF: %.0f wavefronts, %.0f cycles per wavefront (s_memtime)\n", nw, tot / nw);
+    for (int k = 0; k < LKP_N; ++k) fprintf(stderr, "AV_LK_PROF:   %-10s %8.0f cycles per wavefront  %5.1f %%\n", names[k], (double)h[k] / nw, 100. * (double)h[k] / tot);
+    fprintf(stderr, "AV_LK_PROF: per wavefront (max over its 4 points): %.2f levels, %.2f iterations, %.2f J stagings; per point: %.2f iterations, %.2f J stagings\n",
+            (double)h[LKP_LEVELS] / nw, (double)h[LKP_ITERS] / nw, (double)h[LKP_RESTAGES] / nw,
+            (double)h[LKP_SLOTS + 1] / (double)h[LKP_SLOTS], (double)h[LKP_SLOTS + 2] / (double)h[LKP_SLOTS]);
+}
 
 
 // =================================================================================================
@@ -711,8 +787,13 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
     for (int l = 1; l < a.g.levels; ++l)
         if (a.g.w[l] <= p.win || a.g.h[l] <= p.win) { a.g.levels = l; break; }
     a.prev = prev; a.next = next; a.status = status; a.count = count; a.index = index; a.cap = cap;
-    a.max_iter = p.max_iter; a.eps2 = p.eps2; a.min_eig = p.min_eig;
-    a.imgI = imgI; a.imgJ = imgJ; a.imgI_stride = imgI_stride; a.imgJ_stride = imgJ_stride; a.mapI = mapI; a.mapJ = mapJ;
+    a.max_iter = p.max_iter; a.eps2 = p.eps2;
+    a.min_eig_up = (float)p.min_eig;
+    if ((double)a.min_eig_up < p.min_eig) a.min_eig_up = nextafterf(a.min_eig_up, INFINITY);
+    if (p.eps2 >= 1e-30) { a.eps_lo = (float)(p.eps2 * (1. - 0x1p-18)); a.eps_hi = (float)(p.eps2 * (1. + 0x1p-18)); }
+    else { a.eps_lo = -1.f; a.eps_hi = INFINITY; }                 // e32 may underflow: every test in fp64
+    a.min_eig = p.min_eig;
+    a.imgI = imgI; a.imgJ = imgJ; a.imgI_stride = imgI_stride; a.imgJ_stride = imgJ_stride; a.mapI = mapI; a.mapJ = mapJ; a.prof = nullptr;
     if (launch_pts > cap) launch_pts = cap;
     if (p.win != 15) {           // any other window of config.win_size: the general kernel (one wavefront per point)
         a.n_set = n_set; a.gx = 0;
@@ -725,7 +806,18 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
     a.n_set = n_set; a.gx = xcd_map ? gx : 0;
     dim3 grid = xcd_map ? dim3((unsigned)gx * 8u * (unsigned)((n_set + 7) / 8)) : dim3(gx, n_set);
     static const bool w4 = [] { const char* e = getenv("AV_LK_WAVES"); return e && atoi(e) == 4; }();
-    if (w4) hipLaunchKernelGGL(lk_track_g16_kernel_w4<15>, grid, dim3(256), 0, st, a);
+    static const bool prof = [] {
+        const char* e = getenv("AV_LK_PROF");
+        if (!(e && atoi(e) == 1)) return false;
+        if (hipMalloc(&g_lk_prof, sizeof(unsigned long long) * (LKP_SLOTS + 3)) != hipSuccess) { g_lk_prof = nullptr; return false; }
+        (void)hipMemset(g_lk_prof, 0, sizeof(unsigned long long) * (LKP_SLOTS + 3));
+        (void)hipDeviceSynchronize();
+        atexit(lk_prof_report);
+        return true;
+    }();
+    a.prof = g_lk_prof;
+    if (prof) hipLaunchKernelGGL(lk_track_g16_prof_kernel<15>, grid, dim3(256), 0, st, a);
+    else if (w4) hipLaunchKernelGGL(lk_track_g16_kernel_w4<15>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;

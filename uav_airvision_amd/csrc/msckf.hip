@@ -2206,181 +2206,11 @@ __global__ __launch_bounds__(256) void upd_p_kernel(const UpdArgs* __restrict__ 
             }
         }
 }
-// ================================================================================================
-// The same three products on 48-wide WAVE tiles, one workgroup per stream (round 5).
-// With the reference's 20 camera states every dimension of the update is at most 144 (n <= 141 state columns, k <= 136 rows kept,
-// n_c <= 120 touched columns): three tiles of 48 cover it with 6 % slack where three tiles of 64 leave 30 % of every edge empty
-// (135 = 2 x 64 + 7: the third row and column of 64 x 64 workgroup tiles staged full panels for seven rows of results).  A
-// wavefront owns one 48 x 48 tile, 6 x 6 results per lane (8 x 8 lanes): per panel row six 16-byte LDS reads feed 36 multiply-adds
-// (a 4 x 4 lane tile: four reads per 16 -- the 64-wide kernels ran at the LDS port's limit, one 128-byte access per 64 FMA cycles and
-// SIMD).  All tiles of a stream sit in ONE workgroup (nine wavefronts for T^T, six for the lower triangles of S and P), so every
-// operand panel is fetched from memory once per stream instead of once per tile row / column, and the panel of Y serves both
-// sides of Y^T Y.  Same arithmetic as the 64-wide kernels up to the order of the k-sum (panels of 16 either way: identical).
-// Larger windows (max_cam_states > 20) keep the 64-wide kernels.
-// ================================================================================================
-constexpr int WT = 48, WQ = 16, WNT = 3, WP = WNT * WT + 4;        // tile edge, panel depth, tiles per edge, LDS pitch in doubles (16-byte aligned rows)
-typedef double av_d2 __attribute__((ext_vector_type(2)));
-static inline size_t upd_w48_lds(bool two) { return sizeof(double) * 2 * (two ? 2 : 1) * WQ * WP; }
-
-// NTH threads stage 16 x 144 panels of A (and of B when TWO; else both sides of the product read A's panel), double buffered, the next
-// panel's loads in flight during the products (one LDS-only barrier per panel, as gemm_tile64).  loadA(q, e) / loadB(q, e): element e
-// (0 .. 143) of panel row q, zero outside the operand.  Wave tile (ti, tj): results acc[i][j] = sum_q A(q, 48 ti + 6 ly + i) B(q, 48 tj + 6 lx + j).
-template <int NTH, bool TWO, typename FA, typename FB>
-__device__ __forceinline__ void gemm_wave48(int Q, int ti, int tj, bool active, FA loadA, FB loadB, double (&acc)[6][6], double* lds)
-{
-    constexpr int NE = WQ * WNT * WT, NU = NE / NTH;
-    static_assert(NE % NTH == 0, "panel elements per thread");
-    const int tid = threadIdx.x, lane = tid & 63, ly = lane >> 3, lx = lane & 7;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) acc[i][j] = 0.0;
-    double ra[NU], rb[TWO ? NU : 1];
-    auto fetch = [&](int q0) {
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int idx = tid + NTH * u, q = idx / (WNT * WT), e = idx - q * (WNT * WT);
-            const bool in = q0 + q < Q;
-            ra[u] = in ? loadA(q0 + q, e) : 0.0;
-            if (TWO) rb[u] = in ? loadB(q0 + q, e) : 0.0;
-        }
-    };
-    fetch(0);
-    int buf = 0;
-    for (int q0 = 0; q0 < Q; q0 += WQ) {
-        double* pa = lds + (size_t)buf * (TWO ? 2 : 1) * WQ * WP;
-        double* pb = TWO ? pa + WQ * WP : pa;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int idx = tid + NTH * u, q = idx / (WNT * WT), e = idx - q * (WNT * WT);
-            pa[q * WP + e] = ra[u];
-            if (TWO) pb[q * WP + e] = rb[u];
-        }
-        if (q0 + WQ < Q) fetch(q0 + WQ);                   // in flight during the products below
-        lds_barrier();
-        if (active) {
-            const double* ap = pa + WT * ti + 6 * ly;
-            const double* bp = pb + WT * tj + 6 * lx;
-#pragma unroll
-            for (int q = 0; q < WQ; ++q) {
-                const av_d2 a0 = *reinterpret_cast<const av_d2*>(ap + q * WP), a1 = *reinterpret_cast<const av_d2*>(ap + q * WP + 2), a2 = *reinterpret_cast<const av_d2*>(ap + q * WP + 4);
-                const av_d2 b0 = *reinterpret_cast<const av_d2*>(bp + q * WP), b1 = *reinterpret_cast<const av_d2*>(bp + q * WP + 2), b2 = *reinterpret_cast<const av_d2*>(bp + q * WP + 4);
-                const double av[6] = {a0[0], a0[1], a1[0], a1[1], a2[0], a2[1]}, bv[6] = {b0[0], b0[1], b1[0], b1[1], b2[0], b2[1]};
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_fma(av[i], bv[j], acc[i][j]);
-            }
-        }
-        buf ^= 1;
-    }
-}
-
-// T^T (n x k) = P[:, cols] W: nine wave tiles; then, in the same workgroup, S (k x k, lower) = T^T[cols] ^T-side product needs ALL of
-// T^T, so S is its own kernel below.
-__global__ __launch_bounds__(576) void upd_tt48_kernel(const UpdArgs* __restrict__ arr)
-{
-    AV_FILTER_PRIO();
-    extern __shared__ __attribute__((aligned(16))) double w48_lds[];
-    const UpdArgsG a = upd_load(arr, blockIdx.x);
-    if (a.m <= 0 || a.mode != 0) return;
-    const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc)), n = a.n;
-    const int w = threadIdx.x >> 6, ti = w / WNT, tj = w - ti * WNT;          // rows: state index, columns: stacked row
-    const size_t ldt = a.ldt;
-    double acc[6][6];
-    gemm_wave48<576, true>(a.nc, ti, tj, WT * ti < n && WT * tj < k,
-                           [&](int q, int c) { return c < n ? AV_GD(a.P)[(size_t)AV_GI(a.cols)[q] * a.ld + c] : 0.0; },
-                           [&](int q, int r) { return r < k ? AV_GD(a.W)[(size_t)q * ldt + r] : 0.0; }, acc, w48_lds);
-    const int lane = threadIdx.x & 63, c0 = WT * ti + 6 * (lane >> 3), r0 = WT * tj + 6 * (lane & 7);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int c = c0 + i;
-        if (c >= n) continue;
-        // pairs whose first column is below k (a pair may reach one column past k: inside the row pitch, read by nobody)
-#pragma unroll
-        for (int j = 0; j < 6; j += 2)
-            if (r0 + j < k) { av_d2 o = {acc[i][j], acc[i][j + 1]}; *(av_gptr<av_d2>)(a.T + (size_t)c * a.ld + r0 + j) = o; }
-    }
-}
-
-// S[r][c] = sum_q T^T[cols[q]][r] W[q][c] + s^2 [r == c], tiles on and below the diagonal: six wave tiles
-__global__ __launch_bounds__(384) void upd_s48_kernel(const UpdArgs* __restrict__ arr)
-{
-    AV_FILTER_PRIO();
-    extern __shared__ __attribute__((aligned(16))) double w48_lds[];
-    const UpdArgsG a = upd_load(arr, blockIdx.x);
-    if (a.m <= 0 || a.mode != 0) return;
-    const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
-    const int w = threadIdx.x >> 6, ti = w < 1 ? 0 : (w < 3 ? 1 : 2), tj = w - ti * (ti + 1) / 2;
-    const size_t ldt = a.ldt;
-    double acc[6][6];
-    gemm_wave48<384, true>(a.nc, ti, tj, WT * ti < k,
-                           [&](int q, int r) { return r < k ? AV_GD(a.T)[(size_t)AV_GI(a.cols)[q] * a.ld + r] : 0.0; },
-                           [&](int q, int c) { return c < k ? AV_GD(a.W)[(size_t)q * ldt + c] : 0.0; }, acc, w48_lds);
-    const int lane = threadIdx.x & 63, r0 = WT * ti + 6 * (lane >> 3), c0 = WT * tj + 6 * (lane & 7);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int r = r0 + i;
-        if (r >= k) continue;
-#pragma unroll
-        for (int j = 0; j < 6; j += 2)
-            if (c0 + j < k) {
-                av_d2 o = {acc[i][j] + (c0 + j == r ? a.obs_noise : 0.0), acc[i][j + 1] + (c0 + j + 1 == r ? a.obs_noise : 0.0)};
-                *(av_gptr<av_d2>)(a.Sbuf + (size_t)r * a.ld + c0 + j) = o;          // k <= 144 < ld
-            }
-    }
-}
-
-// P <- sym(P - Y^T Y) in place, dx = Y^T y_r: six wave tiles over ONE operand panel (both sides of the product are rows of Y)
-__global__ __launch_bounds__(384, 3) void upd_p48_kernel(const UpdArgs* __restrict__ arr)
-{
-    AV_FILTER_PRIO();
-    __shared__ __attribute__((aligned(16))) double p48_lds[2 * WQ * WP];
-    const UpdArgsG a = upd_load(arr, blockIdx.x);
-    if (a.m <= 0 || a.mode != 0) return;
-    const int n = a.n, k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
-    const int w = threadIdx.x >> 6, ti = w < 1 ? 0 : (w < 3 ? 1 : 2), tj = w - ti * (ti + 1) / 2;
-    double t[6][6];
-    auto ld_y = [&](int q, int r) { return r < n ? AV_GD(a.Kt)[(size_t)q * a.ld + r] : 0.0; };
-    gemm_wave48<384, false>(k, ti, tj, WT * ti < n, ld_y, ld_y, t, p48_lds);
-    {                                                         // delta_x = Y^T y_r
-        const auto rcol = a.W + (size_t)a.nc * a.ldt;
-        for (int c = threadIdx.x; c < n; c += 384) {
-            double sacc = 0;
-#pragma unroll 8
-            for (int i = 0; i < k; ++i) sacc += a.Kt[(size_t)i * a.ld + c] * rcol[i];
-            a.dx[c] = a.round > 0 ? a.dx[c] + sacc : sacc;
-        }
-    }
-    const int lane = threadIdx.x & 63, R0 = WT * ti + 6 * (lane >> 3), C0 = WT * tj + 6 * (lane & 7);
-    if (R0 < C0 || R0 >= n) return;                           // every unordered pair {(r,c), (c,r)} has one owner: the 6 x 6 sub-tile on or below the diagonal
-    // row by row (all 72 entries of P loaded at once beside the 36 products spilled: 238 registers)
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int r = R0 + i;
-        double pr[6], pm[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int c = C0 + j;
-            const bool in = r < n && c < n;
-            pr[j] = in ? a.P[(size_t)r * a.ld + c] : 0.0;
-            pm[j] = in ? a.P[(size_t)c * a.ld + r] : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int c = C0 + j;
-            if (r < n && c < n) {
-                // (inside a diagonal sub-tile the owner holds (r,c) and (c,r) itself; its products are bitwise symmetric --
-                // the same factors summed in the same order -- and so are the two values it writes: whichever of the two
-                // assignments lands last stores the same value)
-                const double v = ((pr[j] - t[i][j]) + (pm[j] - t[i][j])) / 2.;
-                a.P[(size_t)r * a.ld + c] = v;
-                if (R0 != C0) a.P[(size_t)c * a.ld + r] = v;
-            }
-        }
-        asm volatile("" ::: "memory");
-    }
-}
+// (Round 5 archived experiment, profiles/r05/README.md: the three products on 48-wide WAVE tiles, one 576- / 384-thread workgroup per
+//  stream with 6 x 6 results per lane -- three tiles of 48 cover the n <= 141 / k <= 136 of a 20-camera window with 6 % slack where
+//  three tiles of 64 leave 30 % of every edge empty.  Parity-green, but slower: 148.6 k against 155.8 k frames/s on the driver command,
+//  6.24 against 5.87 ms of exclusive chain time.  One workgroup per stream holding 74 KB of LDS keeps two streams on a CU; the 64-wide
+//  kernels spread a stream's tiles over nine short workgroups that fill the gaps the front-end leaves.)
 static inline size_t upd_solve_lds(int k) { return sizeof(double) * ((size_t)k * (k + 1) / 2 + 8); }
 
 // ================================================================================================
@@ -2913,10 +2743,9 @@ static int msckf_lds_opt_in()
         const void* fns[7] = {reinterpret_cast<const void*>(feature_kernel8), reinterpret_cast<const void*>(feature_kernel4),
                               reinterpret_cast<const void*>(feature_kernel<16>), reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
                               reinterpret_cast<const void*>(update_front_kernel), reinterpret_cast<const void*>(update_front_batch_kernel)};
-        const void* fns2[7] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel),
+        const void* fns2[5] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel),
                                reinterpret_cast<const void*>(upd_chol_kernel), reinterpret_cast<const void*>(upd_info_kernel),
-                               reinterpret_cast<const void*>(upd_gram_chol_kernel),
-                               reinterpret_cast<const void*>(upd_tt48_kernel), reinterpret_cast<const void*>(upd_s48_kernel)};
+                               reinterpret_cast<const void*>(upd_gram_chol_kernel)};
         for (const void* f : fns2) {
             hipFuncAttributes at;
             hipError_t e = hipFuncGetAttributes(&at, f);
