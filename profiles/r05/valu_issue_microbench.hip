@@ -106,9 +106,12 @@
         __syncthreads();                                                                                \
         const uint32_t x = threadIdx.x * 2654435761u + seed, y = x ^ 0x5bd1e995u, z = x >> 3;           \
         PROLOGUE;                                                                                       \
+        const uint64_t r0 = __builtin_amdgcn_s_memrealtime();                                           \
         const uint64_t t0 = __builtin_readcyclecounter();                                               \
         for (int i = 0; i < n; ++i) { BLOCK; }                                                          \
         const uint64_t t1 = __builtin_readcyclecounter();                                               \
+        const uint64_t r1 = __builtin_amdgcn_s_memrealtime();                                           \
+        if (threadIdx.x == 0 && blockIdx.x == 0) out[(size_t)gridDim.x * 4] = r1 - r0;                  \
         uint32_t sink;                                                                                  \
         asm volatile("v_add_u32 %0, v8, v9" : "=v"(sink));                                              \
         if (sink == 0x12345u && seed == -1) lds[0] = sink;                                              \
@@ -186,7 +189,7 @@ int main()
     uint64_t* d_out;
     hipEvent_t ev0, ev1;
     CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
-    std::vector<uint64_t> h((size_t)cus * 8 * 4);
+    std::vector<uint64_t> h((size_t)cus * 8 * 4 + 1);
     CK(hipMalloc(&d_out, h.size() * sizeof(uint64_t)));
     printf("{\"device\": \"%s\", \"cus\": %d, \"instructions_per_wave\": %d, \"unit\": \"cycles (s_memtime) per wave-instruction and SIMD = loop cycles / (instructions x waves per SIMD); median over waves\", \"rows\": [\n", prop.gcnArchName, cus, n * 32);
     bool first = true;
@@ -202,14 +205,17 @@ int main()
             CK(hipDeviceSynchronize());
             float ms = 0;
             CK(hipEventElapsedTime(&ms, ev0, ev1));
-            CK(hipMemcpy(h.data(), d_out, (size_t)blocks * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h.data(), d_out, ((size_t)blocks * 4 + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            const double loop_us = (double)h[(size_t)blocks * 4] / 100.;          // s_memrealtime: constant 100 MHz
+            const double wave0_ticks = (double)h[0];
             std::vector<uint64_t> v(h.begin(), h.begin() + (size_t)blocks * 4);
             std::sort(v.begin(), v.end());
             const double med = (double)v[v.size() / 2] / ((double)n * 32 * W);
             printf(", \"w%d\": %.2f", W, med);
             // the same figure from the wall clock: launch duration (all SIMDs run the same loop) / instructions per SIMD, in ns
             printf(", \"w%d_ns\": %.3f", W, (double)ms * 1e6 / ((double)n * 32 * W));
-            if (W == 5) printf(", \"ticks_per_us\": %.1f", (double)v[v.size() / 2] / ((double)ms * 1e3));
+            // in-kernel: wave 0's loop on both clocks (s_memtime ticks per microsecond of the constant 100 MHz s_memrealtime)
+            if (W == 5) printf(", \"ticks_per_us\": %.1f, \"w5_loop_ns\": %.3f", wave0_ticks / loop_us, loop_us * 1e3 / ((double)n * 32 * W));
         }
         printf("}");
         fflush(stdout);

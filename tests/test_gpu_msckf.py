@@ -134,12 +134,19 @@ def test_end_to_end_matches_reference_golden(dropin, cfg, name):
     flt.close()
 
 
-@pytest.mark.parametrize('groups', [1, 2])
-def test_batched_filters_match_reference_golden_and_oracle(cfg, groups, monkeypatch):
+@pytest.mark.parametrize('groups,store', [(1, 'device'), (2, 'device'), (1, 'host'), (2, 'host')])
+def test_batched_filters_match_reference_golden_and_oracle(cfg, groups, store, monkeypatch):
     """Three independent streams stepped together by the C++/HIP batched filter: stream 0 reproduces the
     reference's own golden run; all streams follow the numpy oracle frame by frame.  groups=2 splits the batch
-    into two concurrently stepped stream groups (streams {0,1} and {2}), as large batches are by default."""
+    into two concurrently stepped stream groups (streams {0,1} and {2}), as large batches are by default.
+    store='host' runs the same checks through the host-bookkeeping path (AV_MSCKF_STORE=host: the observation map and the
+    selections on the host, the numeric phases by the same kernels) -- the fallback for shapes the device-resident store
+    does not cover; it stays in the library only as long as it stays tested."""
     monkeypatch.setenv('AV_MSCKF_GROUPS', str(groups))
+    if store == 'host':
+        monkeypatch.setenv('AV_MSCKF_STORE', 'host')
+    else:
+        monkeypatch.delenv('AV_MSCKF_STORE', raising=False)
     from oracle.msckf_np import OracleMSCKF
     from uav_airvision_amd.msckf_ops import BatchedMSCKF
     from uav_airvision_amd.synth import SyntheticFeatureStream
@@ -150,6 +157,7 @@ def test_batched_filters_match_reference_golden_and_oracle(cfg, groups, monkeypa
                SyntheticFeatureStream(cfg, seed=22, n_frames=n_frames, n_features=140)]
     S = len(streams)
     bat = BatchedMSCKF(cfg, S)
+    assert bat.device_resident() == (store == 'device')
     oras = [OracleMSCKF(cfg) for _ in streams]
     its = [iter(s.imu) for s in streams]
     pend = [next(it, None) for it in its]

@@ -264,6 +264,92 @@ __device__ __forceinline__ void jdiff5(uint32_t T0, uint32_t T1, uint32_t T2, ui
 #undef AV_SL
 }
 
+// This lane's row of the I patch and of the two Scharr derivative patches from staged rows r .. r+2 of the window's 18 x 18-byte
+// neighbourhood (load_row(t, B): the five dwords of staged row r + t, byte 0 = window column -1), and the lane's share of the
+// normal-equation sums.  Shared by the two 16-lane kernels (register-staged and LDS-DMA-staged).
+template <int WIN, typename LoadRow>
+__device__ __forceinline__ void lk_patch_rows(LoadRow load_row, uint32_t wtop, uint32_t wbot, int ipx, int ipy, int w, int h, int r,
+                                              int (&iv)[WIN], uint32_t (&ixy)[WIN], int& a11, int& a12, int& a22)
+{
+    constexpr int W_BITS = 14;
+    a11 = 0; a12 = 0; a22 = 0;
+    // staged byte index of window column c is c+1.  E[t][k] = (byte 2k | byte 2k+1 << 16) of staged row r+t; the window
+    // pair (c, c+1) of the centre row is O1[k] = (byte 2k+1 | byte 2k+2 << 16) for c = 2k and E[1][k+1] for c = 2k+1.
+    uint32_t E[3][9];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        uint32_t B[5];
+        load_row(t, B);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {                // bytes 2k, 2k+1
+            const int b0 = 2 * k;
+            E[t][k] = __builtin_amdgcn_perm(0, B[b0 >> 2], 0x0C000C00u | (uint32_t)(b0 & 3) | ((uint32_t)((b0 & 3) + 1) << 16));
+        }
+    }
+    // (hi half of x | lo half of y << 16): the pair one column to the right of x, given y = the next pair
+    auto mid = [](uint32_t x, uint32_t y) -> uint32_t { return __builtin_amdgcn_perm(y, x, 0x05040302u); };
+    // pixel pairs (c, c+1) of the centre row, c = 0..14
+    uint32_t px[WIN];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) px[2 * k] = mid(E[1][k], E[1][k + 1]);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) px[2 * k + 1] = E[1][k + 1];
+    // Scharr on the even window columns (pairs c = 2k, 2k+1); the odd-aligned pairs are byte permutes of those:
+    //   gx[c] = t0[s+1] - t0[s-1],  gy[c] = (t1[s+1] + t1[s-1]) * 3 + t1[s] * 10,  s = c+1,
+    //   t0 = (row above + row below) * 3 + row * 10,  t1 = row below - row above
+    uint32_t gxp[WIN + 1], gyp[WIN + 1];
+    {
+        uint32_t t0E[9], t1E[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            t0E[k] = pk_add(pk_mul(pk_add(E[0][k], E[2][k]), 3), pk_mul(E[1][k], 10));
+            t1E[k] = pk_sub(E[2][k], E[0][k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                 // window columns (2k, 2k+1): centres O[k], left E[k], right E[k+1]
+            gxp[2 * k] = pk_sub(t0E[k + 1], t0E[k]);
+            gyp[2 * k] = pk_add(pk_mul(pk_add(t1E[k + 1], t1E[k]), 3), pk_mul(mid(t1E[k], t1E[k + 1]), 10));
+        }
+    }
+    // the derivative image is zero outside the image: only windows at the border pay for the masks
+    const bool inside = ipx >= 0 && ipx + WIN < w && ipy >= 0 && ipy + WIN < h;
+    if (__builtin_amdgcn_ballot_w64(!inside) != 0) {
+        // the masks are built from an opaque copy of ipx made INSIDE the block: without it the compiler hoists the 60-odd
+        // compares / selects of the mask values onto the common path and keeps only the 16 ANDs in here
+        int ipx_o = ipx;
+        asm volatile("" : "+v"(ipx_o));
+        const bool rowin = (unsigned)(ipy + r) < (unsigned)h;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t m0 = (rowin && (unsigned)(ipx_o + 2 * k) < (unsigned)w) ? 0xFFFFu : 0u;
+            const uint32_t m1 = (rowin && (unsigned)(ipx_o + 2 * k + 1) < (unsigned)w) ? 0xFFFF0000u : 0u;
+            gxp[2 * k] &= (m0 | m1); gyp[2 * k] &= (m0 | m1);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        gxp[2 * k + 1] = mid(gxp[2 * k], gxp[2 * k + 2]);
+        gyp[2 * k + 1] = mid(gyp[2 * k], gyp[2 * k + 2]);
+    }
+    const int rnd_i = 1 << (W_BITS - 6), rnd_d = 1 << (W_BITS - 1);      // rounding terms, one register each
+#pragma unroll
+    for (int c = 0; c < WIN; c += 5) {
+        int ix_[5], iy_[5];
+        bilin5_seed(px[c], px[c + 1], px[c + 2], px[c + 3], px[c + 4], wtop, wbot, rnd_i, iv[c], iv[c + 1], iv[c + 2], iv[c + 3], iv[c + 4]);
+        bilin5<W_BITS>(gxp[c], gxp[c + 1], gxp[c + 2], gxp[c + 3], gxp[c + 4], wtop, wbot, rnd_d, ix_[0], ix_[1], ix_[2], ix_[3], ix_[4]);
+        bilin5<W_BITS>(gyp[c], gyp[c + 1], gyp[c + 2], gyp[c + 3], gyp[c + 4], wtop, wbot, rnd_d, iy_[0], iy_[1], iy_[2], iy_[3], iy_[4]);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) ixy[c + u] = __builtin_amdgcn_perm((uint32_t)iy_[u], (uint32_t)ix_[u], 0x05040100u);
+    }
+#pragma unroll
+    for (int c = 0; c < WIN; ++c) {
+        a11 = mad16<0, 0>(ixy[c], ixy[c], a11);
+        a12 = mad16<0, 1>(ixy[c], ixy[c], a12);
+        a22 = mad16<1, 1>(ixy[c], ixy[c], a22);
+    }
+    if (r >= WIN) { a11 = 0; a12 = 0; a22 = 0; }
+}
+
 template <int WIN, int OCC, bool PROF = false>
 __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
 {
@@ -273,7 +359,8 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
     // phase stamps (PROF only): cycles since the previous stamp are booked on the phase that just ended
     unsigned pt[LKP_N] = {0, 0, 0, 0, 0}, plast = 0;             // 32-bit: a wavefront lives ~10^5 cycles
     unsigned pn_iter = 0, pn_restage = 0, pn_level = 0;
-    if (PROF) plast = (unsigned)__builtin_readcyclecounter();
+    unsigned long long rt0 = 0;
+    if (PROF) { rt0 = __builtin_amdgcn_s_memrealtime(); plast = (unsigned)__builtin_readcyclecounter(); }
 #define LK_STAMP(ph) do { if (PROF) { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); pt[ph] += t_ - plast; plast = t_; } } while (0)
     const int g = threadIdx.x >> 4;                 // point slot of this 16-lane group inside the workgroup
     const int r = threadIdx.x & 15;                 // window row owned by this lane (row 15 only feeds row 14)
@@ -374,86 +461,12 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
         // ---- this lane's row of the I patch and of the Scharr patches: staged rows r..r+2, 18 bytes of each -------------
         int iv[WIN];
         uint32_t ixy[WIN];                        // (Ix | Iy << 16) per window column
-        int a11 = 0, a12 = 0, a22 = 0;
-        {
-            // staged byte index of window column c is c+1.  E[t][k] = (byte 2k | byte 2k+1 << 16) of staged row r+t; the window
-            // pair (c, c+1) of the centre row is O1[k] = (byte 2k+1 | byte 2k+2 << 16) for c = 2k and E[1][k+1] for c = 2k+1.
-            uint32_t E[3][9];
+        int a11, a12, a22;
+        lk_patch_rows<WIN>([&](int t, uint32_t (&B)[5]) {
+                               const uint32_t* rowp = tile + __mul24(r + t, TPITCH / 4);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const uint32_t* rowp = tile + __mul24(r + t, TPITCH / 4);
-                uint32_t B[5];
-#pragma unroll
-                for (int k = 0; k < 5; ++k) B[k] = rowp[k];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {                // bytes 2k, 2k+1
-                    const int b0 = 2 * k;
-                    E[t][k] = __builtin_amdgcn_perm(0, B[b0 >> 2], 0x0C000C00u | (uint32_t)(b0 & 3) | ((uint32_t)((b0 & 3) + 1) << 16));
-                }
-            }
-            // (hi half of x | lo half of y << 16): the pair one column to the right of x, given y = the next pair
-            auto mid = [](uint32_t x, uint32_t y) -> uint32_t { return __builtin_amdgcn_perm(y, x, 0x05040302u); };
-            // pixel pairs (c, c+1) of the centre row, c = 0..14
-            uint32_t px[WIN];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) px[2 * k] = mid(E[1][k], E[1][k + 1]);
-#pragma unroll
-            for (int k = 0; k < 7; ++k) px[2 * k + 1] = E[1][k + 1];
-            // Scharr on the even window columns (pairs c = 2k, 2k+1); the odd-aligned pairs are byte permutes of those:
-            //   gx[c] = t0[s+1] - t0[s-1],  gy[c] = (t1[s+1] + t1[s-1]) * 3 + t1[s] * 10,  s = c+1,
-            //   t0 = (row above + row below) * 3 + row * 10,  t1 = row below - row above
-            uint32_t gxp[WIN + 1], gyp[WIN + 1];
-            {
-                uint32_t t0E[9], t1E[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    t0E[k] = pk_add(pk_mul(pk_add(E[0][k], E[2][k]), 3), pk_mul(E[1][k], 10));
-                    t1E[k] = pk_sub(E[2][k], E[0][k]);
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {                 // window columns (2k, 2k+1): centres O[k], left E[k], right E[k+1]
-                    gxp[2 * k] = pk_sub(t0E[k + 1], t0E[k]);
-                    gyp[2 * k] = pk_add(pk_mul(pk_add(t1E[k + 1], t1E[k]), 3), pk_mul(mid(t1E[k], t1E[k + 1]), 10));
-                }
-            }
-            // the derivative image is zero outside the image: only windows at the border pay for the masks
-            const bool inside = ipx >= 0 && ipx + WIN < w && ipy >= 0 && ipy + WIN < h;
-            if (__builtin_amdgcn_ballot_w64(!inside) != 0) {
-                // the masks are built from an opaque copy of ipx made INSIDE the block: without it the compiler hoists the 60-odd
-                // compares / selects of the mask values onto the common path and keeps only the 16 ANDs in here
-                int ipx_o = ipx;
-                asm volatile("" : "+v"(ipx_o));
-                const bool rowin = (unsigned)(ipy + r) < (unsigned)h;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t m0 = (rowin && (unsigned)(ipx_o + 2 * k) < (unsigned)w) ? 0xFFFFu : 0u;
-                    const uint32_t m1 = (rowin && (unsigned)(ipx_o + 2 * k + 1) < (unsigned)w) ? 0xFFFF0000u : 0u;
-                    gxp[2 * k] &= (m0 | m1); gyp[2 * k] &= (m0 | m1);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                gxp[2 * k + 1] = mid(gxp[2 * k], gxp[2 * k + 2]);
-                gyp[2 * k + 1] = mid(gyp[2 * k], gyp[2 * k + 2]);
-            }
-            const int rnd_i = 1 << (W_BITS - 6), rnd_d = 1 << (W_BITS - 1);      // rounding terms, one register each
-#pragma unroll
-            for (int c = 0; c < WIN; c += 5) {
-                int ix_[5], iy_[5];
-                bilin5_seed(px[c], px[c + 1], px[c + 2], px[c + 3], px[c + 4], wtop, wbot, rnd_i, iv[c], iv[c + 1], iv[c + 2], iv[c + 3], iv[c + 4]);
-                bilin5<W_BITS>(gxp[c], gxp[c + 1], gxp[c + 2], gxp[c + 3], gxp[c + 4], wtop, wbot, rnd_d, ix_[0], ix_[1], ix_[2], ix_[3], ix_[4]);
-                bilin5<W_BITS>(gyp[c], gyp[c + 1], gyp[c + 2], gyp[c + 3], gyp[c + 4], wtop, wbot, rnd_d, iy_[0], iy_[1], iy_[2], iy_[3], iy_[4]);
-#pragma unroll
-                for (int u = 0; u < 5; ++u) ixy[c + u] = __builtin_amdgcn_perm((uint32_t)iy_[u], (uint32_t)ix_[u], 0x05040100u);
-            }
-#pragma unroll
-            for (int c = 0; c < WIN; ++c) {
-                a11 = mad16<0, 0>(ixy[c], ixy[c], a11);
-                a12 = mad16<0, 1>(ixy[c], ixy[c], a12);
-                a22 = mad16<1, 1>(ixy[c], ixy[c], a22);
-            }
-            if (!rowact) { a11 = 0; a12 = 0; a22 = 0; }
-        }
+                               for (int k = 0; k < 5; ++k) B[k] = rowp[k];
+                           }, wtop, wbot, ipx, ipy, w, h, r, iv, ixy, a11, a12, a22);
         const float A11 = row_sum16_scaled(a11);
         const float A12 = row_sum16_scaled(a12);
         const float A22 = row_sum16_scaled(a22);
@@ -577,6 +590,331 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
         if (book && (threadIdx.x & 63) == 0) {
             for (int k = 0; k < LKP_N; ++k) atomicAdd(a.prof + k, (unsigned long long)pt[k]);
             atomicAdd(a.prof + LKP_WAVES, 1ull);
+            atomicAdd(a.prof + LKP_SLOTS + 3, __builtin_amdgcn_s_memrealtime() - rt0);      // the same span on the constant 100 MHz clock
+            atomicAdd(a.prof + LKP_ITERS, (unsigned long long)wi);
+            atomicAdd(a.prof + LKP_RESTAGES, (unsigned long long)wr);
+            atomicAdd(a.prof + LKP_LEVELS, (unsigned long long)wl);
+        }
+        if (book && r == 0) { atomicAdd(a.prof + LKP_SLOTS, 1ull); atomicAdd(a.prof + LKP_SLOTS + 1, (unsigned long long)pn_iter); atomicAdd(a.prof + LKP_SLOTS + 2, (unsigned long long)pn_restage); }
+    }
+#undef LK_STAMP
+}
+
+// =================================================================================================
+// The same kernel with both stagings taken off the wavefront's critical path by LDS-DMA (round 5).
+// Phase stamps of the register-staged kernel (AV_LK_PROF=1, profiles/r05/lk_phase_stamps.txt): a wavefront spends 10.5 % of its life
+// in the I staging and 10.8 % in the J staging -- global_load -> VGPR -> ds_write -> wait, once per level each, with nothing of
+// its own to issue meanwhile -- against 17.7 % in the patch set-up and 51.8 % in the Newton iterations.  Neither address depends
+// on the work it waits behind: the I neighbourhood of level l-1 is a function of prevPt alone, the first J tile of a level of
+// the point's position when the level starts.  So:
+//   * the J tile of a level is requested BEFORE the level's patch set-up and lands while the set-up computes,
+//   * the I neighbourhood of the NEXT level is requested before the level's Newton iterations and lands while they run,
+// both as global_load_lds_dword pieces (no VGPR destination: the kernel stays at 96 registers), into two LDS regions per
+// wavefront (I and J; a region is free again exactly when its next request is issued).  A piece is one wave-instruction: 64
+// dwords, lane-linear -- lane 16 g + 8 sub + d holds dword d of row 2k + sub of the wavefront's point g -- and consecutive pieces
+// lie LKD_KS = 65 dwords apart, so that the 16 rows a point's lanes read in one ds_read fall on 16 different banks (pieces 64
+// apart put every second row on the same bank).  Rows are staged as ALIGNED dwords (the DMA cannot shift): the I rows carry six
+// dwords from the dword that holds window column -1 and the set-up realigns them with v_alignbyte (15 per level).
+// The window bytes, every arithmetic step and their order are those of lk_track_g16_body: results are bit-identical.
+// Needs dword-aligned level-0 rows when level 0 is read from the caller's image (av_launch_lk checks; else the register-staged kernel).
+// =================================================================================================
+constexpr int LKD_KS = 65, LKD_IP = 9, LKD_JP = TILE_ROWS / 2;
+constexpr int LKD_I = LKD_IP * LKD_KS, LKD_J = LKD_JP * LKD_KS, LKD_WAVE = LKD_I + LKD_J;       // 585 + 780 dwords per wavefront
+
+// N pieces in one statement: piece k moves, for every active lane i, the dword at base + voff + k * step to LDS byte address
+// lds + 260 k + 4 i (base, step, lds wave-uniform; 260 = 4 LKD_KS).  M0 holds the LDS address of an LDS-DMA; it is the compiler's
+// register: saved and restored around the pieces.  The v_add between two pieces is also the wait state an LDS-DMA needs after
+// the SALU write of M0.
+#define LKD_P1 "s_add_u32 m0, m0, 0x104\n\tv_add_u32 %1, %3, %1\n\tglobal_load_lds_dword %1, %2\n\t"
+#define LKD_P2 LKD_P1 LKD_P1
+#define LKD_P4 LKD_P2 LKD_P2
+#define LKD_P8 LKD_P4 LKD_P4
+template <int N> __device__ __forceinline__ void lkd_pieces(uint32_t voff, uint32_t step, const uint8_t* base, uint32_t lds)
+{
+    static_assert(N == 9 || N == 12, "piece counts of the I and J regions");
+    unsigned keep;
+    // (the v_add and s_add of a piece are ordered add-then-load: the load of piece k reads voff + k step and M0 + 260 k)
+    if (N == 9)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\t" LKD_P8 "s_mov_b32 m0, %0"
+                     : "=&s"(keep), "+v"(voff) : "s"(base), "s"(step), "s"(lds) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\t" LKD_P8 LKD_P2 LKD_P1 "s_mov_b32 m0, %0"
+                     : "=&s"(keep), "+v"(voff) : "s"(base), "s"(step), "s"(lds) : "memory");
+}
+// all but the N youngest vector-memory operations of this wavefront have completed (LDS-DMA pieces land in issue order)
+template <int N> __device__ __forceinline__ void lkd_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+// every LDS read this wavefront has issued has returned: a region may be overwritten
+__device__ __forceinline__ void lkd_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); }
+
+template <int WIN, bool PROF = false>
+__device__ __forceinline__ void lk_track_g16_dma_body(const LKArgs& a)
+{
+    static_assert(WIN == 15, "lane map is built for the reference's 15x15 window");
+    constexpr int W_BITS = 14;
+    __shared__ uint32_t lds_all[4][LKD_WAVE];
+    unsigned pt[LKP_N] = {0, 0, 0, 0, 0}, plast = 0;
+    unsigned pn_iter = 0, pn_restage = 0, pn_level = 0;
+    unsigned long long rt0 = 0;
+    if (PROF) { rt0 = __builtin_amdgcn_s_memrealtime(); plast = (unsigned)__builtin_readcyclecounter(); }
+#define LK_STAMP(ph) do { if (PROF) { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); pt[ph] += t_ - plast; plast = t_; } } while (0)
+    const int g = threadIdx.x >> 4;                 // point slot of this 16-lane group inside the workgroup
+    const int r = threadIdx.x & 15;                 // window row owned by this lane (row 15 only feeds row 14)
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t* const Ireg = lds_all[wv];
+    uint32_t* const Jreg = Ireg + LKD_I;
+    typedef __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
+    const uint32_t ldsI = (uint32_t)(uintptr_t)(lds_u32_ptr)(&lds_all[0][0]) + (uint32_t)wv * (uint32_t)(LKD_WAVE * 4);
+    const uint32_t ldsJ = ldsI + (uint32_t)(LKD_I * 4);
+    int s, bx;
+    if (a.gx > 0) { const int L = blockIdx.x, j = L >> 3; s = (L & 7) + 8 * (j / a.gx); bx = j % a.gx; if (s >= a.n_set) return; }
+    else { s = blockIdx.y; bx = blockIdx.x; }
+    const int slot = bx * 16 + g;
+    const int sI = a.mapI ? a.mapI[s] : s, sJ = a.mapJ ? a.mapJ[s] : s;
+    if (sI < 0 || sJ < 0) return;
+    const int n = min(a.count[s], a.cap);
+    if (slot >= n) return;                          // uniform per 16-lane group
+    const int pidx = a.index ? a.index[(size_t)s * a.cap + slot] : slot;
+
+    const uint8_t* PI = a.pyrI + sI * a.stream_stride;
+    const uint8_t* PJ = a.pyrJ + sJ * a.stream_stride;
+    const size_t pi = (size_t)s * a.cap + pidx;
+    const float prevx0 = a.prev[2 * pi], prevy0 = a.prev[2 * pi + 1];
+    float curx = a.next[2 * pi], cury = a.next[2 * pi + 1];
+    const float halfWin = (WIN - 1) * 0.5f;
+    const bool rowact = r < WIN;
+    bool ok = true;
+    const uint32_t sel0 = 0x0C010C00u, sel1 = 0x0C020C01u, sel2 = 0x0C030C02u, sel3 = 0x0C040C03u;
+    const int sub = r >> 3, dwl = r & 7;
+    const uint32_t pofs = (uint32_t)(threadIdx.x & 63);      // this lane's dword inside a piece: 16 (g & 3) + 8 sub + dwl
+    const uint32_t gofs = (uint32_t)(16 * (g & 3));          // first dword of this lane's point inside a piece
+
+    // geometry of the I neighbourhood of a level: window origin, source of the rows, whether the window takes the aligned fast path
+    struct IGeo { int ipx, ipy; bool inb, fast; const uint8_t* L0; int pI, bI; };
+    auto i_geo = [&](int level) -> IGeo {
+        IGeo q;
+        const int w = a.g.w[level], h = a.g.h[level];
+        const float scale = __int_as_float((127 - level) << 23);
+        const float pvx = prevx0 * scale - halfWin, pvy = prevy0 * scale - halfWin;
+        q.ipx = (int)floorf(pvx); q.ipy = (int)floorf(pvy);
+        q.inb = !(q.ipx < -WIN || q.ipx >= w || q.ipy < -WIN || q.ipy >= h);
+        const bool extI = level == 0 && a.imgI != nullptr;                      // wave-uniform
+        q.L0 = extI ? a.imgI + (size_t)sI * (size_t)a.imgI_stride : PI + a.g.off[level];
+        q.pI = extI ? w : a.g.pitch[level]; q.bI = extI ? 0 : AV_PYR_BORDER;
+        // padded level: every byte of the six aligned dwords lies inside the padded row (ipx - 1 >= -16, the row's pitch is a multiple
+        // of 16 >= w + 32); caller's image: only windows whose 18 rows x 24 aligned bytes lie inside the image
+        q.fast = !extI || (q.ipx >= 1 && q.ipy >= 1 && q.ipy + 16 < h && ((q.ipx - 1) & ~3) + 24 <= w);
+        return q;
+    };
+    // request the I neighbourhood of a level: rows ipy - 1 .. ipy + 16, six aligned dwords from the one that holds column ipx - 1
+    auto issue_I = [&](int level) {
+        const IGeo q = i_geo(level);
+        // (pitches are multiples of 4: an aligned dword lies wholly inside the row or wholly outside it; the sixth dword of a window at the
+        //  right end of a padded row may start past the row -- it then holds no byte the window needs and is not requested)
+        const bool ld = q.inb && q.fast && dwl < 6 && ((q.ipx - 1 + q.bI) & ~3) + 4 * dwl < q.pI;
+        if (ld) {
+            const uint32_t v0 = (uint32_t)(__mul24(q.ipy - 1 + sub + q.bI, q.pI) + ((q.ipx - 1 + q.bI) & ~3) + 4 * dwl);
+            lkd_pieces<LKD_IP>(v0, (uint32_t)(2 * q.pI), q.L0, ldsI);
+        }
+    };
+
+    issue_I(a.g.levels - 1);
+    for (int level = a.g.levels - 1; level >= 0; --level) {
+        const int w = a.g.w[level], h = a.g.h[level], pitch = a.g.pitch[level];
+        const int col_lo = -AV_PYR_BORDER, col_hi = pitch - AV_PYR_BORDER;
+        const float scale = __int_as_float((127 - level) << 23);
+        if (level == a.g.levels - 1) { curx = curx * scale; cury = cury * scale; }
+        else                         { curx = curx * 2.f;   cury = cury * 2.f; }
+        const IGeo q = i_geo(level);
+        const int ipx = q.ipx, ipy = q.ipy;
+        LK_STAMP(LKP_HEAD);
+        if (PROF) ++pn_level;
+
+        // ---- the J tile of the first Newton step: requested now, read after the set-up -------------------------------------
+        const bool extJ = level == 0 && a.imgJ != nullptr;                      // wave-uniform
+        const uint8_t* LJ0 = extJ ? a.imgJ + (size_t)sJ * (size_t)a.imgJ_stride : PJ + a.g.off[level];
+        const int pJ = extJ ? w : pitch, bJ = extJ ? 0 : AV_PYR_BORDER;
+        int X0 = 0, Y0 = 0;
+        bool staged = false, jslow = false;
+        {
+            const int inx = (int)floorf(curx - halfWin), iny = (int)floorf(cury - halfWin);
+            if (q.inb && !(inx < -WIN || inx >= w || iny < -WIN || iny >= h)) {
+                X0 = min(max((inx - 6) & ~3, col_lo), col_hi - TILE_COLS);
+                Y0 = min(max(iny - 4, -AV_PYR_BORDER), h + AV_PYR_BORDER - TILE_ROWS);
+                staged = true;
+                jslow = extJ && !(X0 >= 0 && X0 + TILE_COLS <= w && Y0 >= 0 && Y0 + TILE_ROWS <= h);
+            }
+        }
+        const bool ldJ = staged && !jslow;
+        const bool anyJ = __builtin_amdgcn_ballot_w64(ldJ) != 0;                // the twelve pieces below are issued by this wavefront
+        lkd_reads_done();                                                       // (the previous level's reads of the J region)
+        if (ldJ) {
+            const uint32_t v0 = (uint32_t)(__mul24(Y0 + sub + bJ, pJ) + X0 + bJ + 4 * dwl);
+            lkd_pieces<LKD_JP>(v0, (uint32_t)(2 * pJ), LJ0, ldsJ);
+        }
+        // ---- the I neighbourhood (requested one level ago) has landed once only the J pieces are outstanding -----------------
+        if (anyJ) lkd_wait<LKD_JP>(); else lkd_wait<0>();
+        LK_STAMP(LKP_ISTAGE);
+
+        bool run = q.inb;
+        if (!q.inb && level == 0) ok = false;
+        int iv[WIN];
+        uint32_t ixy[WIN];
+        float A11 = 0.f, A12 = 0.f, A22 = 0.f, D = 0.f;
+        if (run) {
+            const float pvx = prevx0 * scale - halfWin, pvy = prevy0 * scale - halfWin;
+            const float fa = pvx - ipx, fb = pvy - ipy;
+            const int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+            const int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+            const int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+            const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            const uint32_t wtop = pack16(iw00, iw01), wbot = pack16(iw10, iw11);
+            uint32_t o = (uint32_t)(ipx - 1 + q.bI) & 3u;                       // byte of window column -1 inside its dword
+            if (!q.fast) {
+                // the window reaches over the border of the caller's image: the bytes a padded level's BORDER_REFLECT_101 frame would
+                // hold, gathered byte by byte and stored with column -1 at byte 0 (o = 0)
+                o = 0;
+                if (dwl < 5) {
+                    const int xb = ipx - 1 + (dwl < 4 ? 4 * dwl : 16), nbyte = dwl < 4 ? 4 : 2;
+#pragma unroll 1
+                    for (int k = 0; k < LKD_IP; ++k) {
+                        const uint8_t* row = q.L0 + (size_t)av_reflect101(ipy - 1 + sub + 2 * k, h) * (size_t)w;
+                        uint32_t v = 0;
+#pragma unroll 1
+                        for (int bb = 0; bb < nbyte; ++bb) v |= (uint32_t)row[av_reflect101(xb + bb, w)] << (8 * bb);
+                        Ireg[k * LKD_KS + pofs] = v;
+                    }
+                }
+                wave_lds_sync();
+            }
+            int a11, a12, a22;
+            lk_patch_rows<WIN>([&](int t, uint32_t (&B)[5]) {
+                                   const int R = r + t;
+                                   const uint32_t* rowp = Ireg + __mul24(R >> 1, LKD_KS) + 8 * (R & 1) + gofs;
+                                   uint32_t B6[6];
+#pragma unroll
+                                   for (int k = 0; k < 6; ++k) B6[k] = rowp[k];
+#pragma unroll
+                                   for (int k = 0; k < 5; ++k) B[k] = __builtin_amdgcn_alignbyte(B6[k + 1], B6[k], o);
+                               }, wtop, wbot, ipx, ipy, w, h, r, iv, ixy, a11, a12, a22);
+            A11 = row_sum16_scaled(a11);
+            A12 = row_sum16_scaled(a12);
+            A22 = row_sum16_scaled(a22);
+            D = A11 * A22 - A12 * A12;
+            const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+            if (minEig < a.min_eig_up || D < 1.1920928955078125e-7f) {
+                if (level == 0) ok = false;
+                run = false;
+            }
+        }
+        LK_STAMP(LKP_SETUP);
+        // ---- the J tile has landed; the I region is free: request the next level's neighbourhood, it lands during the iterations ----
+        lkd_wait<0>();
+        if (level > 0) { lkd_reads_done(); issue_I(level - 1); }
+        LK_STAMP(LKP_JSTAGE);
+        if (run) {
+            D = 1.f / D;
+            float wx = curx - halfWin, wy = cury - halfWin;
+            float pdx = 0.f, pdy = 0.f;
+            bool fresh = jslow;                      // the first tile still has to be gathered (caller's image, tile over its border)
+            for (int j = 0; j < a.max_iter; ++j) {
+                if (PROF) ++pn_iter;
+                const int inx = (int)floorf(wx), iny = (int)floorf(wy);
+                if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) {
+                    if (level == 0) ok = false;
+                    break;
+                }
+                int dx0 = inx - X0, dy0 = iny - Y0;
+                const bool moved = !staged || (unsigned)dx0 > (unsigned)(TILE_COLS - 17) || (unsigned)dy0 > (unsigned)(TILE_ROWS - 16);
+                if (moved || fresh) {
+                    if (moved) {
+                        X0 = min(max((inx - 6) & ~3, col_lo), col_hi - TILE_COLS);
+                        Y0 = min(max(iny - 4, -AV_PYR_BORDER), h + AV_PYR_BORDER - TILE_ROWS);
+                    }
+                    fresh = false;
+                    if (PROF) ++pn_restage;
+                    wave_lds_sync();
+                    if (!extJ || (X0 >= 0 && X0 + TILE_COLS <= w && Y0 >= 0 && Y0 + TILE_ROWS <= h)) {
+                        // (rare: the window drifted off its tile.  Requested and waited for on the spot; the wait also drains the next
+                        //  level's I pieces)
+                        lkd_reads_done();
+                        const uint32_t v0 = (uint32_t)(__mul24(Y0 + sub + bJ, pJ) + X0 + bJ + 4 * dwl);
+                        lkd_pieces<LKD_JP>(v0, (uint32_t)(2 * pJ), LJ0, ldsJ);
+                        lkd_wait<0>();
+                    } else {
+#pragma unroll 1
+                        for (int k = 0; k < LKD_JP; ++k) {
+                            const uint8_t* row = LJ0 + (size_t)av_reflect101(Y0 + sub + 2 * k, h) * (size_t)w;
+                            uint32_t v = 0;
+#pragma unroll 1
+                            for (int bb = 0; bb < 4; ++bb) v |= (uint32_t)row[av_reflect101(X0 + 4 * dwl + bb, w)] << (8 * bb);
+                            Jreg[k * LKD_KS + pofs] = v;
+                        }
+                    }
+                    wave_lds_sync();
+                    staged = true;
+                    dx0 = inx - X0; dy0 = iny - Y0;
+                }
+                const float fa = wx - inx, fb = wy - iny;
+                const int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
+                const int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
+                const int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
+                const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+                const uint32_t wtop = pack16(iw00, iw01), wbot = pack16(iw10, iw11);
+
+                // this lane's J row (dy0 + r): 16 pixels starting at byte dx0 -> 5 aligned dwords -> 4 byte-aligned dwords
+                const int sh = dx0 & 3, R = dy0 + r;
+                const uint32_t* rp = Jreg + __mul24(R >> 1, LKD_KS) + 8 * (R & 1) + gofs + (dx0 >> 2);
+                uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2], d3 = rp[3], d4 = rp[4];
+                const uint32_t T0 = __builtin_amdgcn_alignbyte(d1, d0, sh), T1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                const uint32_t T2 = __builtin_amdgcn_alignbyte(d3, d2, sh), T3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+                int df[WIN];
+                jdiff5<0>(T0, T1, T2, T3, sel0, sel1, sel2, sel3, wtop, wbot, iv[0], iv[1], iv[2], iv[3], iv[4], df[0], df[1], df[2], df[3], df[4]);
+                jdiff5<5>(T0, T1, T2, T3, sel0, sel1, sel2, sel3, wtop, wbot, iv[5], iv[6], iv[7], iv[8], iv[9], df[5], df[6], df[7], df[8], df[9]);
+                jdiff5<10>(T0, T1, T2, T3, sel0, sel1, sel2, sel3, wtop, wbot, iv[10], iv[11], iv[12], iv[13], iv[14], df[10], df[11], df[12], df[13], df[14]);
+                int b1 = 0, b2 = 0;
+#pragma unroll
+                for (int c = 0; c < WIN; ++c) {
+                    b1 = mad16<0, 0>((uint32_t)df[c], ixy[c], b1);
+                    b2 = mad16<0, 1>((uint32_t)df[c], ixy[c], b2);
+                }
+                if (!rowact) { b1 = 0; b2 = 0; }
+                const float fb1 = row_sum16_scaled(b1);
+                const float fb2 = row_sum16_scaled(b2);
+                const float dx = (A12 * fb2 - A22 * fb1) * D;
+                const float dy = (A12 * fb1 - A11 * fb2) * D;
+                wx += dx; wy += dy;
+                curx = wx + halfWin; cury = wy + halfWin;
+                const float e32 = __builtin_fmaf(dx, dx, dy * dy);
+                bool conv = e32 <= a.eps_lo;
+                if (__builtin_amdgcn_ballot_w64(e32 > a.eps_lo && e32 < a.eps_hi) != 0) {
+                    asm volatile("; fp64 step test");
+                    conv = (double)dx * dx + (double)dy * dy <= a.eps2;
+                }
+                if (conv) break;
+                if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
+                    curx -= dx * 0.5f; cury -= dy * 0.5f;
+                    break;
+                }
+                pdx = dx; pdy = dy;
+            }
+        }
+        LK_STAMP(LKP_ITER);
+    }
+    if (r == 0) {
+        a.next[2 * pi] = curx;
+        a.next[2 * pi + 1] = cury;
+        a.status[pi] = ok ? 1 : 0;
+    }
+    if (PROF) {
+        LK_STAMP(LKP_HEAD);
+        unsigned wi = pn_iter, wr = pn_restage, wl = pn_level;
+#pragma unroll
+        for (int d = 16; d < 64; d <<= 1) { wi = max(wi, (unsigned)__shfl_xor((int)wi, d, 64)); wr = max(wr, (unsigned)__shfl_xor((int)wr, d, 64)); wl = max(wl, (unsigned)__shfl_xor((int)wl, d, 64)); }
+        const bool book = blockIdx.x % 61 == 0;
+        if (book && (threadIdx.x & 63) == 0) {
+            for (int k = 0; k < LKP_N; ++k) atomicAdd(a.prof + k, (unsigned long long)pt[k]);
+            atomicAdd(a.prof + LKP_WAVES, 1ull);
+            atomicAdd(a.prof + LKP_SLOTS + 3, __builtin_amdgcn_s_memrealtime() - rt0);
             atomicAdd(a.prof + LKP_ITERS, (unsigned long long)wi);
             atomicAdd(a.prof + LKP_RESTAGES, (unsigned long long)wr);
             atomicAdd(a.prof + LKP_LEVELS, (unsigned long long)wl);
@@ -589,25 +927,28 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
 // 96 VGPRs: 5 waves per SIMD without spills (the kernel is VALU-issue bound: 4 -> 5 waves bought 1 %, a 6-wave build with
 // 11 spilled values lost 5 %).
 template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_kernel(LKArgs a) { lk_track_g16_body<WIN, 5>(a); }
-// A/B (AV_LK_WAVES=4): the same body held to four waves per SIMD -- 128 of a SIMD's 512 VGPR rows stay free, room for one wave of
-// the filter's fp64 kernels (64-128 VGPRs) beside four LK waves; with five LK waves (480 rows) no filter wave fits until one retires.
-template <int WIN> __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(256) void lk_track_g16_kernel_w4(LKArgs a) { lk_track_g16_body<WIN, 4>(a); }
+// (a four-wave build that leaves 128 register rows per SIMD to the filter's kernels: 146.7 k against 152.8 k frames/s, round 4)
 // AV_LK_PROF=1: the same body with s_memtime stamps at the phase boundaries (I staging / patch set-up / J staging / Newton
 // iterations), summed over the wavefronts of every launch and printed at exit (profiles/r05/lk_phase_stamps.txt).
 template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_prof_kernel(LKArgs a) { lk_track_g16_body<WIN, 5, true>(a); }
+// the LDS-DMA-staged kernel (default) and its stamped form (AV_LK_PROF=1)
+template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_dma_kernel(LKArgs a) { lk_track_g16_dma_body<WIN>(a); }
+template <int WIN> __global__ __launch_bounds__(256, 6) void lk_track_g16_dma6_kernel(LKArgs a) { lk_track_g16_dma_body<WIN>(a); }     // A/B: AV_LK_DMA=6
+template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_dma_prof_kernel(LKArgs a) { lk_track_g16_dma_body<WIN, true>(a); }
 
 static unsigned long long* g_lk_prof = nullptr;
 static void lk_prof_report()
 {
     if (!g_lk_prof) return;
-    unsigned long long h[LKP_SLOTS + 3];
+    unsigned long long h[LKP_SLOTS + 4];
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, g_lk_prof, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
     static const char* names[LKP_N] = {"head+tail", "I staging", "set-up", "J staging", "iterations"};
     double tot = 0;
     for (int k = 0; k < LKP_N; ++k) tot += (double)h[k];
     const double nw = (double)h[LKP_WAVES];
-    fprintf(stderr, "AV_LK_PROF: %.0f wavefronts, %.0f cycles per wavefront (s_memtime)\n", nw, tot / nw);
-    for (int k = 0; k < LKP_N; ++k) fprintf(stderr, "AV_LK_PROF:   %-10s %8.0f cycles per wavefront  %5.1f %%\n", names[k], (double)h[k] / nw, 100. * (double)h[k] / tot);
+    fprintf(stderr, "AV_LK_PROF: %.0f wavefronts booked (one workgroup in 61), %.0f s_memtime ticks per wavefront = %.1f us on the 100 MHz clock: %.0f ticks per us\n",
+            nw, tot / nw, (double)h[LKP_SLOTS + 3] / nw / 100., tot / ((double)h[LKP_SLOTS + 3] / 100.));
+    for (int k = 0; k < LKP_N; ++k) fprintf(stderr, "AV_LK_PROF:   %-10s %8.0f ticks per wavefront  %5.1f %%\n", names[k], (double)h[k] / nw, 100. * (double)h[k] / tot);
     fprintf(stderr, "AV_LK_PROF: per wavefront (max over its 4 points): %.2f levels, %.2f iterations, %.2f J stagings; per point: %.2f iterations, %.2f J stagings\n",
             (double)h[LKP_LEVELS] / nw, (double)h[LKP_ITERS] / nw, (double)h[LKP_RESTAGES] / nw,
             (double)h[LKP_SLOTS + 1] / (double)h[LKP_SLOTS], (double)h[LKP_SLOTS + 2] / (double)h[LKP_SLOTS]);
@@ -805,19 +1146,25 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
     const int gx = (launch_pts + 15) / 16;
     a.n_set = n_set; a.gx = xcd_map ? gx : 0;
     dim3 grid = xcd_map ? dim3((unsigned)gx * 8u * (unsigned)((n_set + 7) / 8)) : dim3(gx, n_set);
-    static const bool w4 = [] { const char* e = getenv("AV_LK_WAVES"); return e && atoi(e) == 4; }();
     static const bool prof = [] {
         const char* e = getenv("AV_LK_PROF");
         if (!(e && atoi(e) == 1)) return false;
-        if (hipMalloc(&g_lk_prof, sizeof(unsigned long long) * (LKP_SLOTS + 3)) != hipSuccess) { g_lk_prof = nullptr; return false; }
-        (void)hipMemset(g_lk_prof, 0, sizeof(unsigned long long) * (LKP_SLOTS + 3));
+        if (hipMalloc(&g_lk_prof, sizeof(unsigned long long) * (LKP_SLOTS + 4)) != hipSuccess) { g_lk_prof = nullptr; return false; }
+        (void)hipMemset(g_lk_prof, 0, sizeof(unsigned long long) * (LKP_SLOTS + 4));
         (void)hipDeviceSynchronize();
         atexit(lk_prof_report);
         return true;
     }();
     a.prof = g_lk_prof;
-    if (prof) hipLaunchKernelGGL(lk_track_g16_prof_kernel<15>, grid, dim3(256), 0, st, a);
-    else if (w4) hipLaunchKernelGGL(lk_track_g16_kernel_w4<15>, grid, dim3(256), 0, st, a);
+    // LDS-DMA staging needs dword-aligned level-0 rows when level 0 is the caller's image (padded levels always are).  AV_LK_DMA=0: A/B.
+    static const bool dma_env = [] { const char* e = getenv("AV_LK_DMA"); return e && atoi(e) != 0; }();      // measured slower (profiles/r05/lk_dma_experiment.md): off
+    static const bool dma6 = [] { const char* e = getenv("AV_LK_DMA"); return e && atoi(e) == 6; }();
+    auto al4 = [&](const uint8_t* img, int64_t stride) { return !img || (((uintptr_t)img | (uintptr_t)stride | (uintptr_t)g.w[0]) & 3) == 0; };
+    const bool dma = dma_env && al4(imgI, imgI_stride) && al4(imgJ, imgJ_stride) && (((uintptr_t)pyrI | (uintptr_t)pyrJ | (uintptr_t)stream_stride) & 3) == 0;
+    if (dma && prof) hipLaunchKernelGGL(lk_track_g16_dma_prof_kernel<15>, grid, dim3(256), 0, st, a);
+    else if (dma && dma6) hipLaunchKernelGGL(lk_track_g16_dma6_kernel<15>, grid, dim3(256), 0, st, a);
+    else if (dma) hipLaunchKernelGGL(lk_track_g16_dma_kernel<15>, grid, dim3(256), 0, st, a);
+    else if (prof) hipLaunchKernelGGL(lk_track_g16_prof_kernel<15>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;

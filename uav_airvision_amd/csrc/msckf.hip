@@ -822,13 +822,9 @@ template <> __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bound
 // The device-resident filter's build of the 16-lane kernel: 207 registers, nothing spilled, two waves per SIMD.  Measured per 2,048-stream
 // launch (round 4, profiles/r04/README.md): 564 us, against 688 us at 128 registers (256 B of scratch per lane), 814 at 96, 920 at 80 --
 // PMC showed 73 % of the wave cycles waiting on memory, and the spill traffic was part of what they waited for.
-__global__ __attribute__((amdgpu_waves_per_eu(2, 3))) __launch_bounds__(256) void feature_kernel16_w3(FeatArgs a) { feature_body<16>(a); }
 // eight and four lanes per two-observation feature (8 / 16 features per wavefront): the Jacobian phase keeps 2 lanes of a team busy and the
 // gate-matrix blocks 4, whatever the team size -- smaller teams waste fewer lanes there and take more rounds in the later phases
 __global__ __attribute__((amdgpu_waves_per_eu(2, 3))) __launch_bounds__(256) void feature_kernel8(FeatArgs a) { feature_body<8>(a); }
-__global__ __attribute__((amdgpu_waves_per_eu(2, 3))) __launch_bounds__(256) void feature_kernel4(FeatArgs a) { feature_body<4>(a); }
-__global__ __attribute__((amdgpu_waves_per_eu(5, 8))) __launch_bounds__(256) void feature_kernel16_w5(FeatArgs a) { feature_body<16>(a); }
-__global__ __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(256) void feature_kernel16_w6(FeatArgs a) { feature_body<16>(a); }
 
 static int msckf_lds_opt_in();       // raises the dynamic-LDS limit of every kernel below once per process
 
@@ -1199,7 +1195,7 @@ constexpr int UPD_BAD_PIVOT = -2;
 // The batched kernels read their UpdArgs from an array in memory, and a pointer that arrives that way is GENERIC to the compiler: every
 // access through it becomes a FLAT load / store, which takes the slower flat path and counts on lgkmcnt (the LDS counter) as well as
 // vmcnt.  UpdArgsG is the same record with its pointers typed as global memory (address space 1: global_load / global_store); the
-// kernels below work on that view, their shared bodies are templates over the record type (dk_prune keeps its UpdArgs in LDS).
+// kernels below work on that view, their shared bodies are templates over the record type (a kernel may keep its UpdArgs in LDS).
 template <typename T> using av_gptr = T __attribute__((address_space(1)))*;
 struct UpdArgsG {
     av_gptr<double> P; int n, ld;
@@ -1835,7 +1831,7 @@ __device__ __forceinline__ void update_back(const UpdArgs& a)
 //   T^T = P[:, cols] H_thin^T   (n x k)      upd_tt_kernel
 //   S   = H_thin P_cc H_thin^T + s^2 I        upd_s_kernel      (rows cols[q] of T^T are exactly P_cc H_thin^T)
 //   L L^T = S                                  upd_chol_kernel   (blocked, LDS)
-//   Y = L^-1 [T | r]                           upd_fsolve_kernel (a lane per right-hand side, L through the scalar cache)
+//   Y = L^-1 [T | r]                           upd_fsolve16_kernel (a lane per right-hand side, L through the scalar cache)
 //   P  <- sym(P - Y^T Y) in place, dx = Y^T y_r   upd_p_kernel
 // fp64 MFMA is not used: on MI355X the fp64 matrix peak equals the fp64 vector peak (78.6 TFLOP/s, CDNA4 halved the
 // MI300's fp64 matrix rate), so v_mfma_f64_16x16x4 buys no throughput over v_fma_f64 and costs the fragment shuffles.
@@ -2149,9 +2145,7 @@ __device__ __forceinline__ void upd_fsolve_body(const UpdArgs* __restrict__ arr)
         }
     }
 }
-__global__ __launch_bounds__(64) void upd_fsolve_kernel(const UpdArgs* __restrict__ arr) { upd_fsolve_body<8>(arr); }
 __global__ __launch_bounds__(64) void upd_fsolve16_kernel(const UpdArgs* __restrict__ arr) { upd_fsolve_body<16>(arr); }
-__global__ __launch_bounds__(64) void upd_fsolve32_kernel(const UpdArgs* __restrict__ arr) { upd_fsolve_body<32>(arr); }
 
 // P <- sym(P - Y^T Y) in place (msckf.py:597-602): the 4 x 4 sub-tiles on and below the diagonal are formed, each owner
 // reads its sub-tile of P and the mirror sub-tile, then writes both -- every unordered pair {(r,c), (c,r)} has one owner.
@@ -2740,7 +2734,7 @@ static int msckf_lds_opt_in()
 {
     static const int rc = [] {
         const int lim = 160 * 1024;
-        const void* fns[7] = {reinterpret_cast<const void*>(feature_kernel8), reinterpret_cast<const void*>(feature_kernel4),
+        const void* fns[6] = {reinterpret_cast<const void*>(feature_kernel8),
                               reinterpret_cast<const void*>(feature_kernel<16>), reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
                               reinterpret_cast<const void*>(update_front_kernel), reinterpret_cast<const void*>(update_front_batch_kernel)};
         const void* fns2[5] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel),
