@@ -597,7 +597,7 @@ def main():
     w_e0 = None
     if flt is not None and Wm > 0:
         if flt.device_resident():
-            w_e0 = flt.work(enable=1)
+            w_e0 = flt.work(enable=1); w_e0.update(flt.work_executed())
             path.force_serial = True
         run_pipelined(PRE, PRE + Wm)
         path.force_serial = False
@@ -607,6 +607,7 @@ def main():
     eng.read_features()
     c_t0 = flt.counters() if flt is not None else None
     w_t0 = flt.work(enable=1) if flt is not None else None      # HIP events around the filter's phase chains from here on
+    if w_t0 is not None: w_t0.update(flt.work_executed())
     eng.enable_timing(16 * (F - PRE - Wm) + 16)
 
     barrier()
@@ -631,6 +632,7 @@ def main():
         sys.stderr.write('[step intervals ms] ' + ' '.join('%.1f' % ((b_ - a_) * 1e3) for a_, b_ in zip(tt[:-1], tt[1:])) + '\n')
     c_t1 = flt.counters() if flt is not None else None
     w_t1 = flt.work(enable=0) if flt is not None else None
+    if w_t1 is not None: w_t1.update(flt.work_executed())
     fe_elapsed = None
     timing_fe = None
     if with_msckf:                                   # same engine state, next K frames, front-end only
@@ -753,6 +755,16 @@ def main():
                 'features_gated_per_stream_step': dw['features_gated'] / K / S, 'rows_stacked_per_update': dw['rows_stacked'] / max(dw['updates'], 1.0),
                 'updates_per_stream_step': dw['updates'] / K / S,
                 'chain_ms_per_step': dw['chain_ms'] / K,
+                # the same stage by the flops the kernels EXECUTE on their block-sparse shapes (av_msckf_batch_work_executed: analytic
+                # per gated feature / per update, tile padding not counted) -- the dense formulas above price a 21-observation gate
+                # at 5.5 MFLOP where feature_kernel runs ~0.6
+                'executed': {'flops_per_step': (dw['gate_flops_executed'] + dw['update_flops_executed']) / K,
+                             'gate_flops_per_step': dw['gate_flops_executed'] / K, 'update_flops_per_step': dw['update_flops_executed'] / K,
+                             'achieved': ((dw['gate_flops_executed'] + dw['update_flops_executed']) / (dw['chain_ms'] * 1e-3) / 1e12) if dw['chain_ms'] > 0 else 0.0,
+                             'frac': ((dw['gate_flops_executed'] + dw['update_flops_executed']) / (dw['chain_ms'] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if dw['chain_ms'] > 0 else 0.0,
+                             'exclusive_frac': None if w_e0 is None or w_t0['chain_ms'] <= w_e0['chain_ms'] else
+                                 ((w_t0['gate_flops_executed'] - w_e0['gate_flops_executed']) + (w_t0['update_flops_executed'] - w_e0['update_flops_executed']))
+                                 / ((w_t0['chain_ms'] - w_e0['chain_ms']) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
                 'exclusive': None if w_e0 is None or w_t0['chain_ms'] <= w_e0['chain_ms'] else {
                     'chain_ms_per_step': (w_t0['chain_ms'] - w_e0['chain_ms']) / Wm,
                     'achieved': ((w_t0['gate_flops'] - w_e0['gate_flops']) + (w_t0['update_flops'] - w_e0['update_flops'])) / ((w_t0['chain_ms'] - w_e0['chain_ms']) * 1e-3) / 1e12,
@@ -797,6 +809,8 @@ def main():
         rm_ = out.get('roofline_msckf')
         if rm_ is not None and not (0.0 <= rm_['frac'] <= 1.0):
             failed.append('roofline_msckf.frac out of range: %r' % rm_['frac'])
+        if rm_ is not None and rm_.get('executed') and not (rm_['executed']['flops_per_step'] <= rm_['algorithmic_flops_per_step']):
+            failed.append('roofline_msckf: executed flops above the dense-formula count: %r > %r' % (rm_['executed']['flops_per_step'], rm_['algorithmic_flops_per_step']))
         if failed:
             out['roofline_check_failed'] = failed
             bench_rc = 3

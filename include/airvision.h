@@ -401,6 +401,14 @@ int  av_msckf_batch_debug_read(av_msckf_batch* b, int stream_idx, int phase, dou
  * covariance update) spent on the device summed over stream groups, 0].  The time needs enable = 1 on an earlier call (two HIP
  * events per phase and group); enable = 0 switches it off, enable < 0 only reads. */
 int  av_msckf_batch_work(av_msckf_batch* b, int enable, double out8[8]);
+/* The same two stages counted as the kernels EXECUTE them (drain first; device-resident path, zeros otherwise): out2 = [fp64 flops of
+ * the gating tests on the block-sparse shapes -- H_x as 4 x 6 blocks, the gate matrix from the M^2 6 x 6 blocks of P, reflectors applied
+ * to it from both sides: ~0.6 MFLOP for a 21-observation track where the dense formula above says 5.5 --, fp64 flops of the updates
+ * over the touched columns -- Gram compression m (nc+1)^2 + (nc+1)^3/3 where a stream stacks more rows than one pass, T^T 2 n nc k,
+ * S k^2 nc, Cholesky k^3/3, substitution k^2 (n+1), P - Y^T Y n^2 k; information form m nc^2 + 4 nc^3 + 2 n nc^2 + 2 n^2 nc].
+ * Analytic per gated feature / per update (upd_stack_kernel), tile padding not counted.  No reference counterpart: bench.py's
+ * roofline_msckf.executed. */
+int  av_msckf_batch_work_executed(av_msckf_batch* b, double out2[2]);
 
 /* Measurement hooks (bench.py's roofline leg; no reference counterpart): when enabled, every
  * launch group of av_frontend_step is bracketed by a HIP event pair ON THE STEP'S STREAM.

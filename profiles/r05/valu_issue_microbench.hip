@@ -8,6 +8,11 @@
 // N x 32 instances of ONE instruction (32 independent destinations, or one dependent chain), s_memtime around the loop;
 // cycles per wave-instruction and SIMD = (t1 - t0) / (N * 32 * W) with all W waves of the SIMD running the same loop.
 //
+// The number of waves per SIMD is pinned by LDS: every workgroup asks for 160 KB / W of it, so exactly W fit a CU, and the grid is
+// 256 CUs x W workgroups = everything resident at once, one wave of each workgroup per SIMD (with a small LDS footprint the dispatcher
+// packed some CUs fuller than others and the per-SIMD figures of the first version came out below the hardware's 2 cycles per v_fma_f32).
+// s_memtime ticks are shader cycles: the ticks_per_us column (s_memtime against the constant 100 MHz s_memrealtime) reads 2,300-2,400.
+//
 //   hipcc --offload-arch=gfx950 -O3 -o valu_issue_microbench valu_issue_microbench.hip && ./valu_issue_microbench > valu_issue_microbench.json
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -101,7 +106,9 @@
 #define KERNEL(NAME, BLOCK)                                                                             \
     __global__ __launch_bounds__(256) void k_##NAME(uint64_t* out, int n, int seed)                     \
     {                                                                                                   \
+        extern __shared__ uint32_t lds_dyn[];                                                           \
         __shared__ uint32_t lds[256];                                                                   \
+        if (seed == -2) lds_dyn[threadIdx.x] = 1;                                                       \
         lds[threadIdx.x] = threadIdx.x * seed;                                                          \
         __syncthreads();                                                                                \
         const uint32_t x = threadIdx.x * 2654435761u + seed, y = x ^ 0x5bd1e995u, z = x >> 3;           \
@@ -185,7 +192,7 @@ int main()
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount, n = 2000;
-    const int waves[] = {1, 2, 4, 5};
+    const int waves[] = {1, 2, 4, 5};       // (W + 1) x (160 KB / W - 256 B) > 160 KB for every W here
     uint64_t* d_out;
     hipEvent_t ev0, ev1;
     CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
@@ -197,10 +204,12 @@ int main()
         printf("%s {\"op\": \"%s\"", first ? "" : ",\n", e.name);
         first = false;
         for (int W : waves) {
-            const int blocks = cus * W;                       // 256-thread workgroups: one wave per SIMD each, W per CU when the grid is one round
-            hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, d_out, 50, 1);      // warm the clock / instruction cache
+            const int blocks = cus * W;                       // 256-thread workgroups: one wave per SIMD each, exactly W per CU (LDS)
+            const size_t dyn = (size_t)(160 * 1024) / W - 1024 - 256;      // + 1 KB static: W x (dyn + static) <= 160 KB < (W + 1) x
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), dyn, 0, d_out, 50, 1);      // warm the clock / instruction cache
             CK(hipEventRecord(ev0, 0));
-            hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, d_out, n, 1);
+            hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), dyn, 0, d_out, n, 1);
             CK(hipEventRecord(ev1, 0));
             CK(hipDeviceSynchronize());
             float ms = 0;

@@ -119,6 +119,7 @@ SIGNATURES = {
     'av_msckf_batch_debug_capture': (C.c_int, [_P, C.c_int]),
     'av_msckf_batch_debug_read': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int32), _P, _P, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'av_msckf_batch_work': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double * 8)]),
+    'av_msckf_batch_work_executed': (C.c_int, [_P, C.POINTER(C.c_double * 2)]),
     'av_msckf_batch_get_state': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double * 32), _P, _P, C.c_int, C.POINTER(C.c_int32)]),
     'av_msckf_batch_stream_status': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.c_char_p, C.c_int]),
     'av_frontend_enable_timing': (C.c_int, [_P, C.c_int]),

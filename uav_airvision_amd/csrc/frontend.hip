@@ -622,9 +622,6 @@ struct av_frontend {
     // frame k+1 runs behind the kernels of frame k (pinned double-buffered H2D of frame pairs)
     struct HostSlot { uint8_t* pin = nullptr; uint8_t* dev = nullptr; hipEvent_t copied = nullptr, consumed = nullptr; bool used = false; };
     HostSlot hs[3]; hipStream_t copy_stream = nullptr; int hs_next = 0;      // three: the slot of frame k is still read (as the previous cam0 image) by step k+1
-    // the detector beside the trackers (AV_FE_FAST_ASYNC=1): FAST reads only the new cam0 image and is first needed by select_kernel, so it
-    // can run on a second stream while the temporal / stereo LK launches run on the step's own (fork behind the pyramids, join ahead of select)
-    hipStream_t fast_stream = nullptr; hipEvent_t fast_fork = nullptr, fast_join = nullptr;
     // Level 0 of a pyramid slot (0 / 1: cam0 of alternating frames, 2: cam1) is either the padded copy inside the slot
     // (l0_img = nullptr) or the caller's image itself, read in place by LK and FAST (zero copy).  In place is possible when the
     // image outlives the step that gets it: always for av_frontend_step_host (the library's own staging slots), and for
@@ -812,18 +809,6 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
         return av_launch_fast(fast_img, sstride, fe->geom.pitch[0], AV_PYR_BORDER, nullptr, 0, S, d.w, d.h, fe->cfg.fast_threshold,
                               nullptr, nullptr, 0, d.tile_kp, d.tile_count, d.counters + CNT_OVF, NCNT, fs);
     };
-    static const bool fast_async = [] { const char* e = getenv("AV_FE_FAST_ASYNC"); return e && atoi(e) != 0; }();
-    if (!frames && fast_async) {
-        if (!fe->fast_stream) {
-            AV_HIP(hipStreamCreateWithFlags(&fe->fast_stream, hipStreamNonBlocking));
-            AV_HIP(hipEventCreateWithFlags(&fe->fast_fork, hipEventDisableTiming));
-            AV_HIP(hipEventCreateWithFlags(&fe->fast_join, hipEventDisableTiming));
-        }
-        AV_HIP(hipEventRecord(fe->fast_fork, st));                      // behind the pyramids, the counter reset and the previous step's select
-        AV_HIP(hipStreamWaitEvent(fe->fast_stream, fe->fast_fork, 0));
-        if ((rc = launch_fast(fe->fast_stream))) return rc;
-        AV_HIP(hipEventRecord(fe->fast_join, fe->fast_stream));
-    }
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(track_prepare_kernel, dim3((d.NT + 255) / 256, S), dim3(256), 0, st, d, par);
       AV_LAUNCH_CHECK(); }
@@ -839,9 +824,10 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(rebin_kernel, dim3(S), dim3(256), 0, st, d, par);
       AV_LAUNCH_CHECK(); }
-    if (!frames && !fast_async) {
-        if ((rc = launch_fast(st))) return rc;
-    } else if (!frames) AV_HIP(hipStreamWaitEvent(st, fe->fast_join, 0));      // (frame store: FAST ran when the frame was uploaded)
+    // (FAST on a second HIP stream beside the temporal / stereo LK launches -- it reads only the new cam0 image and is first needed by
+    //  select_kernel -- was measured in round 5: front-end alone 196.6 k against 205.1 k frames/s, complete path 157.7 against 157.3 k:
+    //  the LK launches slow down by more than the detector's time; profiles/r05/README.md)
+    if (!frames && (rc = launch_fast(st))) return rc;                           // (frame store: FAST ran when the frame was uploaded)
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(select_kernel, dim3(S), dim3(256), sizeof(int) * (3 * d.C + 1 + d.n_tiles + 1), st, d);
       AV_LAUNCH_CHECK(); }
@@ -998,7 +984,6 @@ AV_EXPORT void av_frontend_destroy(av_frontend* fe)
     if (fe->fs.uploaded) (void)hipEventDestroy(fe->fs.uploaded);
     if (fe->fs.stepped) (void)hipEventDestroy(fe->fs.stepped);
     if (fe->copy_stream) (void)hipStreamDestroy(fe->copy_stream);
-    if (fe->fast_stream) { (void)hipStreamDestroy(fe->fast_stream); (void)hipEventDestroy(fe->fast_fork); (void)hipEventDestroy(fe->fast_join); }
     for (int i = 0; i < 8; ++i) {
         if (fe->hH[i]) { (void)hipHostFree(fe->hH[i]); (void)hipEventDestroy(fe->hH_ev[i]); }
     }

@@ -266,7 +266,7 @@ __device__ __forceinline__ void jdiff5(uint32_t T0, uint32_t T1, uint32_t T2, ui
 
 // This lane's row of the I patch and of the two Scharr derivative patches from staged rows r .. r+2 of the window's 18 x 18-byte
 // neighbourhood (load_row(t, B): the five dwords of staged row r + t, byte 0 = window column -1), and the lane's share of the
-// normal-equation sums.  Shared by the two 16-lane kernels (register-staged and LDS-DMA-staged).
+// normal-equation sums.
 template <int WIN, typename LoadRow>
 __device__ __forceinline__ void lk_patch_rows(LoadRow load_row, uint32_t wtop, uint32_t wbot, int ipx, int ipy, int w, int h, int r,
                                               int (&iv)[WIN], uint32_t (&ixy)[WIN], int& a11, int& a12, int& a22)
@@ -351,7 +351,7 @@ __device__ __forceinline__ void lk_patch_rows(LoadRow load_row, uint32_t wtop, u
 }
 
 template <int WIN, int OCC, bool PROF = false>
-__device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
+__device__ __forceinline__ bool lk_track_g16_body(const LKArgs& a)
 {
     static_assert(WIN == 15, "lane map is built for the reference's 15x15 window");
     constexpr int W_BITS = 14;
@@ -371,13 +371,13 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
     // window gather in image order reads 2.6x the image bytes).  The 1-D launch keeps a set's workgroups on ONE XCD: id L ->
     // XCD label L & 7, set = label + 8 * ((L >> 3) / gx), block = (L >> 3) % gx.  Placement only: any mapping is correct.
     int s, bx;
-    if (a.gx > 0) { const int L = blockIdx.x, j = L >> 3; s = (L & 7) + 8 * (j / a.gx); bx = j % a.gx; if (s >= a.n_set) return; }
+    if (a.gx > 0) { const int L = blockIdx.x, j = L >> 3; s = (L & 7) + 8 * (j / a.gx); bx = j % a.gx; if (s >= a.n_set) return false; }
     else { s = blockIdx.y; bx = blockIdx.x; }
     const int slot = bx * 16 + g;
     const int sI = a.mapI ? a.mapI[s] : s, sJ = a.mapJ ? a.mapJ[s] : s;      // storage entries of the two images (scalar loads)
-    if (sI < 0 || sJ < 0) return;
+    if (sI < 0 || sJ < 0) return false;
     const int n = min(a.count[s], a.cap);
-    if (slot >= n) return;                          // uniform per 16-lane group
+    if (slot >= n) return false;                    // uniform per 16-lane group
     const int pidx = a.index ? a.index[(size_t)s * a.cap + slot] : slot;
 
     const uint8_t* PI = a.pyrI + sI * a.stream_stride;
@@ -598,343 +598,23 @@ __device__ __forceinline__ void lk_track_g16_body(const LKArgs& a)
         if (book && r == 0) { atomicAdd(a.prof + LKP_SLOTS, 1ull); atomicAdd(a.prof + LKP_SLOTS + 1, (unsigned long long)pn_iter); atomicAdd(a.prof + LKP_SLOTS + 2, (unsigned long long)pn_restage); }
     }
 #undef LK_STAMP
+    return true;
 }
 
-// =================================================================================================
-// The same kernel with both stagings taken off the wavefront's critical path by LDS-DMA (round 5).
-// Phase stamps of the register-staged kernel (AV_LK_PROF=1, profiles/r05/lk_phase_stamps.txt): a wavefront spends 10.5 % of its life
-// in the I staging and 10.8 % in the J staging -- global_load -> VGPR -> ds_write -> wait, once per level each, with nothing of
-// its own to issue meanwhile -- against 17.7 % in the patch set-up and 51.8 % in the Newton iterations.  Neither address depends
-// on the work it waits behind: the I neighbourhood of level l-1 is a function of prevPt alone, the first J tile of a level of
-// the point's position when the level starts.  So:
-//   * the J tile of a level is requested BEFORE the level's patch set-up and lands while the set-up computes,
-//   * the I neighbourhood of the NEXT level is requested before the level's Newton iterations and lands while they run,
-// both as global_load_lds_dword pieces (no VGPR destination: the kernel stays at 96 registers), into two LDS regions per
-// wavefront (I and J; a region is free again exactly when its next request is issued).  A piece is one wave-instruction: 64
-// dwords, lane-linear -- lane 16 g + 8 sub + d holds dword d of row 2k + sub of the wavefront's point g -- and consecutive pieces
-// lie LKD_KS = 65 dwords apart, so that the 16 rows a point's lanes read in one ds_read fall on 16 different banks (pieces 64
-// apart put every second row on the same bank).  Rows are staged as ALIGNED dwords (the DMA cannot shift): the I rows carry six
-// dwords from the dword that holds window column -1 and the set-up realigns them with v_alignbyte (15 per level).
-// The window bytes, every arithmetic step and their order are those of lk_track_g16_body: results are bit-identical.
-// Needs dword-aligned level-0 rows when level 0 is read from the caller's image (av_launch_lk checks; else the register-staged kernel).
-// =================================================================================================
-constexpr int LKD_KS = 65, LKD_IP = 9, LKD_JP = TILE_ROWS / 2;
-constexpr int LKD_I = LKD_IP * LKD_KS, LKD_J = LKD_JP * LKD_KS, LKD_WAVE = LKD_I + LKD_J;       // 585 + 780 dwords per wavefront
-
-// N pieces in one statement: piece k moves, for every active lane i, the dword at base + voff + k * step to LDS byte address
-// lds + 260 k + 4 i (base, step, lds wave-uniform; 260 = 4 LKD_KS).  M0 holds the LDS address of an LDS-DMA; it is the compiler's
-// register: saved and restored around the pieces.  The v_add between two pieces is also the wait state an LDS-DMA needs after
-// the SALU write of M0.
-#define LKD_P1 "s_add_u32 m0, m0, 0x104\n\tv_add_u32 %1, %3, %1\n\tglobal_load_lds_dword %1, %2\n\t"
-#define LKD_P2 LKD_P1 LKD_P1
-#define LKD_P4 LKD_P2 LKD_P2
-#define LKD_P8 LKD_P4 LKD_P4
-template <int N> __device__ __forceinline__ void lkd_pieces(uint32_t voff, uint32_t step, const uint8_t* base, uint32_t lds)
-{
-    static_assert(N == 9 || N == 12, "piece counts of the I and J regions");
-    unsigned keep;
-    // (the v_add and s_add of a piece are ordered add-then-load: the load of piece k reads voff + k step and M0 + 260 k)
-    if (N == 9)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\t" LKD_P8 "s_mov_b32 m0, %0"
-                     : "=&s"(keep), "+v"(voff) : "s"(base), "s"(step), "s"(lds) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\t" LKD_P8 LKD_P2 LKD_P1 "s_mov_b32 m0, %0"
-                     : "=&s"(keep), "+v"(voff) : "s"(base), "s"(step), "s"(lds) : "memory");
-}
-// all but the N youngest vector-memory operations of this wavefront have completed (LDS-DMA pieces land in issue order)
-template <int N> __device__ __forceinline__ void lkd_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
-// every LDS read this wavefront has issued has returned: a region may be overwritten
-__device__ __forceinline__ void lkd_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); }
-
-template <int WIN, bool PROF = false>
-__device__ __forceinline__ void lk_track_g16_dma_body(const LKArgs& a)
-{
-    static_assert(WIN == 15, "lane map is built for the reference's 15x15 window");
-    constexpr int W_BITS = 14;
-    __shared__ uint32_t lds_all[4][LKD_WAVE];
-    unsigned pt[LKP_N] = {0, 0, 0, 0, 0}, plast = 0;
-    unsigned pn_iter = 0, pn_restage = 0, pn_level = 0;
-    unsigned long long rt0 = 0;
-    if (PROF) { rt0 = __builtin_amdgcn_s_memrealtime(); plast = (unsigned)__builtin_readcyclecounter(); }
-#define LK_STAMP(ph) do { if (PROF) { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); pt[ph] += t_ - plast; plast = t_; } } while (0)
-    const int g = threadIdx.x >> 4;                 // point slot of this 16-lane group inside the workgroup
-    const int r = threadIdx.x & 15;                 // window row owned by this lane (row 15 only feeds row 14)
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t* const Ireg = lds_all[wv];
-    uint32_t* const Jreg = Ireg + LKD_I;
-    typedef __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
-    const uint32_t ldsI = (uint32_t)(uintptr_t)(lds_u32_ptr)(&lds_all[0][0]) + (uint32_t)wv * (uint32_t)(LKD_WAVE * 4);
-    const uint32_t ldsJ = ldsI + (uint32_t)(LKD_I * 4);
-    int s, bx;
-    if (a.gx > 0) { const int L = blockIdx.x, j = L >> 3; s = (L & 7) + 8 * (j / a.gx); bx = j % a.gx; if (s >= a.n_set) return; }
-    else { s = blockIdx.y; bx = blockIdx.x; }
-    const int slot = bx * 16 + g;
-    const int sI = a.mapI ? a.mapI[s] : s, sJ = a.mapJ ? a.mapJ[s] : s;
-    if (sI < 0 || sJ < 0) return;
-    const int n = min(a.count[s], a.cap);
-    if (slot >= n) return;                          // uniform per 16-lane group
-    const int pidx = a.index ? a.index[(size_t)s * a.cap + slot] : slot;
-
-    const uint8_t* PI = a.pyrI + sI * a.stream_stride;
-    const uint8_t* PJ = a.pyrJ + sJ * a.stream_stride;
-    const size_t pi = (size_t)s * a.cap + pidx;
-    const float prevx0 = a.prev[2 * pi], prevy0 = a.prev[2 * pi + 1];
-    float curx = a.next[2 * pi], cury = a.next[2 * pi + 1];
-    const float halfWin = (WIN - 1) * 0.5f;
-    const bool rowact = r < WIN;
-    bool ok = true;
-    const uint32_t sel0 = 0x0C010C00u, sel1 = 0x0C020C01u, sel2 = 0x0C030C02u, sel3 = 0x0C040C03u;
-    const int sub = r >> 3, dwl = r & 7;
-    const uint32_t pofs = (uint32_t)(threadIdx.x & 63);      // this lane's dword inside a piece: 16 (g & 3) + 8 sub + dwl
-    const uint32_t gofs = (uint32_t)(16 * (g & 3));          // first dword of this lane's point inside a piece
-
-    // geometry of the I neighbourhood of a level: window origin, source of the rows, whether the window takes the aligned fast path
-    struct IGeo { int ipx, ipy; bool inb, fast; const uint8_t* L0; int pI, bI; };
-    auto i_geo = [&](int level) -> IGeo {
-        IGeo q;
-        const int w = a.g.w[level], h = a.g.h[level];
-        const float scale = __int_as_float((127 - level) << 23);
-        const float pvx = prevx0 * scale - halfWin, pvy = prevy0 * scale - halfWin;
-        q.ipx = (int)floorf(pvx); q.ipy = (int)floorf(pvy);
-        q.inb = !(q.ipx < -WIN || q.ipx >= w || q.ipy < -WIN || q.ipy >= h);
-        const bool extI = level == 0 && a.imgI != nullptr;                      // wave-uniform
-        q.L0 = extI ? a.imgI + (size_t)sI * (size_t)a.imgI_stride : PI + a.g.off[level];
-        q.pI = extI ? w : a.g.pitch[level]; q.bI = extI ? 0 : AV_PYR_BORDER;
-        // padded level: every byte of the six aligned dwords lies inside the padded row (ipx - 1 >= -16, the row's pitch is a multiple
-        // of 16 >= w + 32); caller's image: only windows whose 18 rows x 24 aligned bytes lie inside the image
-        q.fast = !extI || (q.ipx >= 1 && q.ipy >= 1 && q.ipy + 16 < h && ((q.ipx - 1) & ~3) + 24 <= w);
-        return q;
-    };
-    // request the I neighbourhood of a level: rows ipy - 1 .. ipy + 16, six aligned dwords from the one that holds column ipx - 1
-    auto issue_I = [&](int level) {
-        const IGeo q = i_geo(level);
-        // (pitches are multiples of 4: an aligned dword lies wholly inside the row or wholly outside it; the sixth dword of a window at the
-        //  right end of a padded row may start past the row -- it then holds no byte the window needs and is not requested)
-        const bool ld = q.inb && q.fast && dwl < 6 && ((q.ipx - 1 + q.bI) & ~3) + 4 * dwl < q.pI;
-        if (ld) {
-            const uint32_t v0 = (uint32_t)(__mul24(q.ipy - 1 + sub + q.bI, q.pI) + ((q.ipx - 1 + q.bI) & ~3) + 4 * dwl);
-            lkd_pieces<LKD_IP>(v0, (uint32_t)(2 * q.pI), q.L0, ldsI);
-        }
-    };
-
-    issue_I(a.g.levels - 1);
-    for (int level = a.g.levels - 1; level >= 0; --level) {
-        const int w = a.g.w[level], h = a.g.h[level], pitch = a.g.pitch[level];
-        const int col_lo = -AV_PYR_BORDER, col_hi = pitch - AV_PYR_BORDER;
-        const float scale = __int_as_float((127 - level) << 23);
-        if (level == a.g.levels - 1) { curx = curx * scale; cury = cury * scale; }
-        else                         { curx = curx * 2.f;   cury = cury * 2.f; }
-        const IGeo q = i_geo(level);
-        const int ipx = q.ipx, ipy = q.ipy;
-        LK_STAMP(LKP_HEAD);
-        if (PROF) ++pn_level;
-
-        // ---- the J tile of the first Newton step: requested now, read after the set-up -------------------------------------
-        const bool extJ = level == 0 && a.imgJ != nullptr;                      // wave-uniform
-        const uint8_t* LJ0 = extJ ? a.imgJ + (size_t)sJ * (size_t)a.imgJ_stride : PJ + a.g.off[level];
-        const int pJ = extJ ? w : pitch, bJ = extJ ? 0 : AV_PYR_BORDER;
-        int X0 = 0, Y0 = 0;
-        bool staged = false, jslow = false;
-        {
-            const int inx = (int)floorf(curx - halfWin), iny = (int)floorf(cury - halfWin);
-            if (q.inb && !(inx < -WIN || inx >= w || iny < -WIN || iny >= h)) {
-                X0 = min(max((inx - 6) & ~3, col_lo), col_hi - TILE_COLS);
-                Y0 = min(max(iny - 4, -AV_PYR_BORDER), h + AV_PYR_BORDER - TILE_ROWS);
-                staged = true;
-                jslow = extJ && !(X0 >= 0 && X0 + TILE_COLS <= w && Y0 >= 0 && Y0 + TILE_ROWS <= h);
-            }
-        }
-        const bool ldJ = staged && !jslow;
-        const bool anyJ = __builtin_amdgcn_ballot_w64(ldJ) != 0;                // the twelve pieces below are issued by this wavefront
-        lkd_reads_done();                                                       // (the previous level's reads of the J region)
-        if (ldJ) {
-            const uint32_t v0 = (uint32_t)(__mul24(Y0 + sub + bJ, pJ) + X0 + bJ + 4 * dwl);
-            lkd_pieces<LKD_JP>(v0, (uint32_t)(2 * pJ), LJ0, ldsJ);
-        }
-        // ---- the I neighbourhood (requested one level ago) has landed once only the J pieces are outstanding -----------------
-        if (anyJ) lkd_wait<LKD_JP>(); else lkd_wait<0>();
-        LK_STAMP(LKP_ISTAGE);
-
-        bool run = q.inb;
-        if (!q.inb && level == 0) ok = false;
-        int iv[WIN];
-        uint32_t ixy[WIN];
-        float A11 = 0.f, A12 = 0.f, A22 = 0.f, D = 0.f;
-        if (run) {
-            const float pvx = prevx0 * scale - halfWin, pvy = prevy0 * scale - halfWin;
-            const float fa = pvx - ipx, fb = pvy - ipy;
-            const int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
-            const int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
-            const int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
-            const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-            const uint32_t wtop = pack16(iw00, iw01), wbot = pack16(iw10, iw11);
-            uint32_t o = (uint32_t)(ipx - 1 + q.bI) & 3u;                       // byte of window column -1 inside its dword
-            if (!q.fast) {
-                // the window reaches over the border of the caller's image: the bytes a padded level's BORDER_REFLECT_101 frame would
-                // hold, gathered byte by byte and stored with column -1 at byte 0 (o = 0)
-                o = 0;
-                if (dwl < 5) {
-                    const int xb = ipx - 1 + (dwl < 4 ? 4 * dwl : 16), nbyte = dwl < 4 ? 4 : 2;
-#pragma unroll 1
-                    for (int k = 0; k < LKD_IP; ++k) {
-                        const uint8_t* row = q.L0 + (size_t)av_reflect101(ipy - 1 + sub + 2 * k, h) * (size_t)w;
-                        uint32_t v = 0;
-#pragma unroll 1
-                        for (int bb = 0; bb < nbyte; ++bb) v |= (uint32_t)row[av_reflect101(xb + bb, w)] << (8 * bb);
-                        Ireg[k * LKD_KS + pofs] = v;
-                    }
-                }
-                wave_lds_sync();
-            }
-            int a11, a12, a22;
-            lk_patch_rows<WIN>([&](int t, uint32_t (&B)[5]) {
-                                   const int R = r + t;
-                                   const uint32_t* rowp = Ireg + __mul24(R >> 1, LKD_KS) + 8 * (R & 1) + gofs;
-                                   uint32_t B6[6];
-#pragma unroll
-                                   for (int k = 0; k < 6; ++k) B6[k] = rowp[k];
-#pragma unroll
-                                   for (int k = 0; k < 5; ++k) B[k] = __builtin_amdgcn_alignbyte(B6[k + 1], B6[k], o);
-                               }, wtop, wbot, ipx, ipy, w, h, r, iv, ixy, a11, a12, a22);
-            A11 = row_sum16_scaled(a11);
-            A12 = row_sum16_scaled(a12);
-            A22 = row_sum16_scaled(a22);
-            D = A11 * A22 - A12 * A12;
-            const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
-            if (minEig < a.min_eig_up || D < 1.1920928955078125e-7f) {
-                if (level == 0) ok = false;
-                run = false;
-            }
-        }
-        LK_STAMP(LKP_SETUP);
-        // ---- the J tile has landed; the I region is free: request the next level's neighbourhood, it lands during the iterations ----
-        lkd_wait<0>();
-        if (level > 0) { lkd_reads_done(); issue_I(level - 1); }
-        LK_STAMP(LKP_JSTAGE);
-        if (run) {
-            D = 1.f / D;
-            float wx = curx - halfWin, wy = cury - halfWin;
-            float pdx = 0.f, pdy = 0.f;
-            bool fresh = jslow;                      // the first tile still has to be gathered (caller's image, tile over its border)
-            for (int j = 0; j < a.max_iter; ++j) {
-                if (PROF) ++pn_iter;
-                const int inx = (int)floorf(wx), iny = (int)floorf(wy);
-                if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) {
-                    if (level == 0) ok = false;
-                    break;
-                }
-                int dx0 = inx - X0, dy0 = iny - Y0;
-                const bool moved = !staged || (unsigned)dx0 > (unsigned)(TILE_COLS - 17) || (unsigned)dy0 > (unsigned)(TILE_ROWS - 16);
-                if (moved || fresh) {
-                    if (moved) {
-                        X0 = min(max((inx - 6) & ~3, col_lo), col_hi - TILE_COLS);
-                        Y0 = min(max(iny - 4, -AV_PYR_BORDER), h + AV_PYR_BORDER - TILE_ROWS);
-                    }
-                    fresh = false;
-                    if (PROF) ++pn_restage;
-                    wave_lds_sync();
-                    if (!extJ || (X0 >= 0 && X0 + TILE_COLS <= w && Y0 >= 0 && Y0 + TILE_ROWS <= h)) {
-                        // (rare: the window drifted off its tile.  Requested and waited for on the spot; the wait also drains the next
-                        //  level's I pieces)
-                        lkd_reads_done();
-                        const uint32_t v0 = (uint32_t)(__mul24(Y0 + sub + bJ, pJ) + X0 + bJ + 4 * dwl);
-                        lkd_pieces<LKD_JP>(v0, (uint32_t)(2 * pJ), LJ0, ldsJ);
-                        lkd_wait<0>();
-                    } else {
-#pragma unroll 1
-                        for (int k = 0; k < LKD_JP; ++k) {
-                            const uint8_t* row = LJ0 + (size_t)av_reflect101(Y0 + sub + 2 * k, h) * (size_t)w;
-                            uint32_t v = 0;
-#pragma unroll 1
-                            for (int bb = 0; bb < 4; ++bb) v |= (uint32_t)row[av_reflect101(X0 + 4 * dwl + bb, w)] << (8 * bb);
-                            Jreg[k * LKD_KS + pofs] = v;
-                        }
-                    }
-                    wave_lds_sync();
-                    staged = true;
-                    dx0 = inx - X0; dy0 = iny - Y0;
-                }
-                const float fa = wx - inx, fb = wy - iny;
-                const int iw00 = __float2int_rn((1.f - fa) * (1.f - fb) * (1 << W_BITS));
-                const int iw01 = __float2int_rn(fa * (1.f - fb) * (1 << W_BITS));
-                const int iw10 = __float2int_rn((1.f - fa) * fb * (1 << W_BITS));
-                const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-                const uint32_t wtop = pack16(iw00, iw01), wbot = pack16(iw10, iw11);
-
-                // this lane's J row (dy0 + r): 16 pixels starting at byte dx0 -> 5 aligned dwords -> 4 byte-aligned dwords
-                const int sh = dx0 & 3, R = dy0 + r;
-                const uint32_t* rp = Jreg + __mul24(R >> 1, LKD_KS) + 8 * (R & 1) + gofs + (dx0 >> 2);
-                uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2], d3 = rp[3], d4 = rp[4];
-                const uint32_t T0 = __builtin_amdgcn_alignbyte(d1, d0, sh), T1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-                const uint32_t T2 = __builtin_amdgcn_alignbyte(d3, d2, sh), T3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
-                int df[WIN];
-                jdiff5<0>(T0, T1, T2, T3, sel0, sel1, sel2, sel3, wtop, wbot, iv[0], iv[1], iv[2], iv[3], iv[4], df[0], df[1], df[2], df[3], df[4]);
-                jdiff5<5>(T0, T1, T2, T3, sel0, sel1, sel2, sel3, wtop, wbot, iv[5], iv[6], iv[7], iv[8], iv[9], df[5], df[6], df[7], df[8], df[9]);
-                jdiff5<10>(T0, T1, T2, T3, sel0, sel1, sel2, sel3, wtop, wbot, iv[10], iv[11], iv[12], iv[13], iv[14], df[10], df[11], df[12], df[13], df[14]);
-                int b1 = 0, b2 = 0;
-#pragma unroll
-                for (int c = 0; c < WIN; ++c) {
-                    b1 = mad16<0, 0>((uint32_t)df[c], ixy[c], b1);
-                    b2 = mad16<0, 1>((uint32_t)df[c], ixy[c], b2);
-                }
-                if (!rowact) { b1 = 0; b2 = 0; }
-                const float fb1 = row_sum16_scaled(b1);
-                const float fb2 = row_sum16_scaled(b2);
-                const float dx = (A12 * fb2 - A22 * fb1) * D;
-                const float dy = (A12 * fb1 - A11 * fb2) * D;
-                wx += dx; wy += dy;
-                curx = wx + halfWin; cury = wy + halfWin;
-                const float e32 = __builtin_fmaf(dx, dx, dy * dy);
-                bool conv = e32 <= a.eps_lo;
-                if (__builtin_amdgcn_ballot_w64(e32 > a.eps_lo && e32 < a.eps_hi) != 0) {
-                    asm volatile("; fp64 step test");
-                    conv = (double)dx * dx + (double)dy * dy <= a.eps2;
-                }
-                if (conv) break;
-                if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
-                    curx -= dx * 0.5f; cury -= dy * 0.5f;
-                    break;
-                }
-                pdx = dx; pdy = dy;
-            }
-        }
-        LK_STAMP(LKP_ITER);
-    }
-    if (r == 0) {
-        a.next[2 * pi] = curx;
-        a.next[2 * pi + 1] = cury;
-        a.status[pi] = ok ? 1 : 0;
-    }
-    if (PROF) {
-        LK_STAMP(LKP_HEAD);
-        unsigned wi = pn_iter, wr = pn_restage, wl = pn_level;
-#pragma unroll
-        for (int d = 16; d < 64; d <<= 1) { wi = max(wi, (unsigned)__shfl_xor((int)wi, d, 64)); wr = max(wr, (unsigned)__shfl_xor((int)wr, d, 64)); wl = max(wl, (unsigned)__shfl_xor((int)wl, d, 64)); }
-        const bool book = blockIdx.x % 61 == 0;
-        if (book && (threadIdx.x & 63) == 0) {
-            for (int k = 0; k < LKP_N; ++k) atomicAdd(a.prof + k, (unsigned long long)pt[k]);
-            atomicAdd(a.prof + LKP_WAVES, 1ull);
-            atomicAdd(a.prof + LKP_SLOTS + 3, __builtin_amdgcn_s_memrealtime() - rt0);
-            atomicAdd(a.prof + LKP_ITERS, (unsigned long long)wi);
-            atomicAdd(a.prof + LKP_RESTAGES, (unsigned long long)wr);
-            atomicAdd(a.prof + LKP_LEVELS, (unsigned long long)wl);
-        }
-        if (book && r == 0) { atomicAdd(a.prof + LKP_SLOTS, 1ull); atomicAdd(a.prof + LKP_SLOTS + 1, (unsigned long long)pn_iter); atomicAdd(a.prof + LKP_SLOTS + 2, (unsigned long long)pn_restage); }
-    }
-#undef LK_STAMP
-}
-
+// (Round 5, archived -- profiles/r05/lk_dma_experiment.md, code in git 741c321: both stagings by LDS-DMA, the J tile requested before
+//  the patch set-up and the next level's I neighbourhood before the iterations.  Bit-exact, the wavefront's life 13 % shorter, the
+//  launch 1.7 % LONGER (0.955 vs 0.939 ms): at five wavefronts per SIMD the other four already fill the slots a staging wavefront
+//  leaves; the kernel is bound by VALU issue.)
 // 96 VGPRs: 5 waves per SIMD without spills (the kernel is VALU-issue bound: 4 -> 5 waves bought 1 %, a 6-wave build with
 // 11 spilled values lost 5 %).
 template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_kernel(LKArgs a) { lk_track_g16_body<WIN, 5>(a); }
+// (Forward and backward pass of a stereo match as ONE launch -- the 16 lanes that tracked a point forward track it back, three launches
+//  fewer per front-end step -- was built and measured in round 5: front-end alone 207.9 / 206.2 k against 206.1 / 206.8 k frames/s, one
+//  stream 0.649 against 0.645 ms per frame: nothing, removed.  profiles/r05/README.md)
 // (a four-wave build that leaves 128 register rows per SIMD to the filter's kernels: 146.7 k against 152.8 k frames/s, round 4)
 // AV_LK_PROF=1: the same body with s_memtime stamps at the phase boundaries (I staging / patch set-up / J staging / Newton
 // iterations), summed over the wavefronts of every launch and printed at exit (profiles/r05/lk_phase_stamps.txt).
 template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_prof_kernel(LKArgs a) { lk_track_g16_body<WIN, 5, true>(a); }
-// the LDS-DMA-staged kernel (default) and its stamped form (AV_LK_PROF=1)
-template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_dma_kernel(LKArgs a) { lk_track_g16_dma_body<WIN>(a); }
-template <int WIN> __global__ __launch_bounds__(256, 6) void lk_track_g16_dma6_kernel(LKArgs a) { lk_track_g16_dma_body<WIN>(a); }     // A/B: AV_LK_DMA=6
-template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_dma_prof_kernel(LKArgs a) { lk_track_g16_dma_body<WIN, true>(a); }
 
 static unsigned long long* g_lk_prof = nullptr;
 static void lk_prof_report()
@@ -1113,14 +793,12 @@ __global__ __launch_bounds__(256) void lk_track_generic_kernel(LKArgs a, int WIN
 
 }  // namespace
 
-int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride, int n_set, const PyrGeom& g,
-                 const float* prev, float* next, uint8_t* status, const int* count, int cap, int launch_pts,
-                 const LKParams& p, hipStream_t st, const int* index,
-                 const uint8_t* imgI, int64_t imgI_stride, const uint8_t* imgJ, int64_t imgJ_stride, const int* mapI, const int* mapJ)
+static int lk_fill_args(LKArgs& a, const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride, const PyrGeom& g,
+                        const float* prev, float* next, uint8_t* status, const int* count, int cap,
+                        const LKParams& p, const int* index,
+                        const uint8_t* imgI, int64_t imgI_stride, const uint8_t* imgJ, int64_t imgJ_stride, const int* mapI, const int* mapJ)
 {
-    if (n_set <= 0 || launch_pts <= 0) return AV_OK;
     if (p.win < 3 || p.win > LKG_MAX_WIN) { av_set_error("av_lk_track: winSize %d outside 3 .. %d", p.win, LKG_MAX_WIN); return AV_E_INVALID; }
-    LKArgs a;
     a.pyrI = pyrI; a.pyrJ = pyrJ; a.stream_stride = stream_stride; a.g = g;
     // cv::buildOpticalFlowPyramid stops at the first level whose successor would be no larger than the window in either
     // dimension (OpenCV 4.x lkpyramid.cpp: `if (sz.width <= winSize.width || sz.height <= winSize.height) return level`);
@@ -1135,17 +813,12 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
     else { a.eps_lo = -1.f; a.eps_hi = INFINITY; }                 // e32 may underflow: every test in fp64
     a.min_eig = p.min_eig;
     a.imgI = imgI; a.imgJ = imgJ; a.imgI_stride = imgI_stride; a.imgJ_stride = imgJ_stride; a.mapI = mapI; a.mapJ = mapJ; a.prof = nullptr;
-    if (launch_pts > cap) launch_pts = cap;
-    if (p.win != 15) {           // any other window of config.win_size: the general kernel (one wavefront per point)
-        a.n_set = n_set; a.gx = 0;
-        hipLaunchKernelGGL(lk_track_generic_kernel, dim3((launch_pts + 3) / 4, n_set), dim3(256), 0, st, a, p.win);
-        AV_LAUNCH_CHECK();
-        return AV_OK;
-    }
-    static const bool xcd_map = [] { const char* e = getenv("AV_LK_XCD"); return !(e && atoi(e) == 0); }();      // A/B switch
-    const int gx = (launch_pts + 15) / 16;
-    a.n_set = n_set; a.gx = xcd_map ? gx : 0;
-    dim3 grid = xcd_map ? dim3((unsigned)gx * 8u * (unsigned)((n_set + 7) / 8)) : dim3(gx, n_set);
+    a.n_set = 0; a.gx = 0;
+    return AV_OK;
+}
+
+static bool lk_prof_on()
+{
     static const bool prof = [] {
         const char* e = getenv("AV_LK_PROF");
         if (!(e && atoi(e) == 1)) return false;
@@ -1155,16 +828,38 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
         atexit(lk_prof_report);
         return true;
     }();
+    return prof;
+}
+
+// grid of the 16-lane kernels: XCD-aware 1-D launch (lk_track_g16_body) unless AV_LK_XCD=0
+static dim3 lk_g16_grid(LKArgs& a, int n_set, int launch_pts)
+{
+    static const bool xcd_map = [] { const char* e = getenv("AV_LK_XCD"); return !(e && atoi(e) == 0); }();      // A/B switch
+    const int gx = (launch_pts + 15) / 16;
+    a.n_set = n_set; a.gx = xcd_map ? gx : 0;
+    return xcd_map ? dim3((unsigned)gx * 8u * (unsigned)((n_set + 7) / 8)) : dim3(gx, n_set);
+}
+
+int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride, int n_set, const PyrGeom& g,
+                 const float* prev, float* next, uint8_t* status, const int* count, int cap, int launch_pts,
+                 const LKParams& p, hipStream_t st, const int* index,
+                 const uint8_t* imgI, int64_t imgI_stride, const uint8_t* imgJ, int64_t imgJ_stride, const int* mapI, const int* mapJ)
+{
+    if (n_set <= 0 || launch_pts <= 0) return AV_OK;
+    LKArgs a;
+    int rc = lk_fill_args(a, pyrI, pyrJ, stream_stride, g, prev, next, status, count, cap, p, index, imgI, imgI_stride, imgJ, imgJ_stride, mapI, mapJ);
+    if (rc) return rc;
+    if (launch_pts > cap) launch_pts = cap;
+    if (p.win != 15) {           // any other window of config.win_size: the general kernel (one wavefront per point)
+        a.n_set = n_set; a.gx = 0;
+        hipLaunchKernelGGL(lk_track_generic_kernel, dim3((launch_pts + 3) / 4, n_set), dim3(256), 0, st, a, p.win);
+        AV_LAUNCH_CHECK();
+        return AV_OK;
+    }
+    const dim3 grid = lk_g16_grid(a, n_set, launch_pts);
+    const bool prof = lk_prof_on();
     a.prof = g_lk_prof;
-    // LDS-DMA staging needs dword-aligned level-0 rows when level 0 is the caller's image (padded levels always are).  AV_LK_DMA=0: A/B.
-    static const bool dma_env = [] { const char* e = getenv("AV_LK_DMA"); return e && atoi(e) != 0; }();      // measured slower (profiles/r05/lk_dma_experiment.md): off
-    static const bool dma6 = [] { const char* e = getenv("AV_LK_DMA"); return e && atoi(e) == 6; }();
-    auto al4 = [&](const uint8_t* img, int64_t stride) { return !img || (((uintptr_t)img | (uintptr_t)stride | (uintptr_t)g.w[0]) & 3) == 0; };
-    const bool dma = dma_env && al4(imgI, imgI_stride) && al4(imgJ, imgJ_stride) && (((uintptr_t)pyrI | (uintptr_t)pyrJ | (uintptr_t)stream_stride) & 3) == 0;
-    if (dma && prof) hipLaunchKernelGGL(lk_track_g16_dma_prof_kernel<15>, grid, dim3(256), 0, st, a);
-    else if (dma && dma6) hipLaunchKernelGGL(lk_track_g16_dma6_kernel<15>, grid, dim3(256), 0, st, a);
-    else if (dma) hipLaunchKernelGGL(lk_track_g16_dma_kernel<15>, grid, dim3(256), 0, st, a);
-    else if (prof) hipLaunchKernelGGL(lk_track_g16_prof_kernel<15>, grid, dim3(256), 0, st, a);
+    if (prof) hipLaunchKernelGGL(lk_track_g16_prof_kernel<15>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;

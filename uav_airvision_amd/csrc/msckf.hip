@@ -825,6 +825,10 @@ template <> __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bound
 // eight and four lanes per two-observation feature (8 / 16 features per wavefront): the Jacobian phase keeps 2 lanes of a team busy and the
 // gate-matrix blocks 4, whatever the team size -- smaller teams waste fewer lanes there and take more rounds in the later phases
 __global__ __attribute__((amdgpu_waves_per_eu(2, 3))) __launch_bounds__(256) void feature_kernel8(FeatArgs a) { feature_body<8>(a); }
+// A/B (AV_FILTER_V128 bit 0): the same kernel held to 128 registers.  Beside the LK kernel (five waves of 96 registers per SIMD, a deep
+// backlog of workgroups) a 207-register wave needs TWO retiring LK waves of one SIMD that the LK queue does not refill in between; a
+// 128-register wave fits the hole one retiring wave leaves (96 + the 32 spare rows).
+__global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(256) void feature_kernel8_v128(FeatArgs a) { feature_body<8>(a); }
 
 static int msckf_lds_opt_in();       // raises the dynamic-LDS limit of every kernel below once per process
 
@@ -2236,7 +2240,14 @@ __global__ __launch_bounds__(256) void upd_info_kernel(const UpdArgs* __restrict
     if (a.m <= 0 || a.mode != 1) return;
     upd_info_body(a, Li_dyn);
 }
-// (also called by the fused pruning kernel of the device-resident filter, msckf_dev.inc: dk_prune)
+__global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(256) void upd_info_v128_kernel(const UpdArgs* __restrict__ arr)      // A/B (AV_FILTER_V128 bit 1)
+{
+    AV_FILTER_PRIO();
+    extern __shared__ double Li_dyn[];
+    const UpdArgsG a = upd_load(arr, blockIdx.x);
+    if (a.m <= 0 || a.mode != 1) return;
+    upd_info_body(a, Li_dyn);
+}
 template <typename UA> __device__ __forceinline__ void upd_info_body(const UA& a, double* Li)
 {
     const int tid = threadIdx.x, n = a.n, nc = a.nc, nb = a.n_blk;
@@ -2599,7 +2610,7 @@ struct StackArgs {
     const int* over;                         // [S] 1: the stream's candidates reserved more rows than the block buffer holds, so they were
     int* row_off_w; int* again_list; int* again_count;   //  gated without storage (row_off = -1): the stacked ones get compact offsets here and are listed to run again
     int* clist; int* clist_count;            // out: streams whose stacked rows exceed one back-end pass (compression kernels stride over this list)
-    double* work;                            // [S][8] accumulators of av_msckf_batch_work: gate flops, update flops, reference-QR flops, gated, updates, rows
+    double* work;                            // [S][8] accumulators of av_msckf_batch_work: gate flops, update flops, reference-QR flops, gated, updates, rows; [6], [7]: executed gate / update flops (av_msckf_batch_work_executed)
     int hld;                                 // UpdArgs::hld of this phase's updates (0: dense rows)
     int no_info;                             // 1: this phase launches no information-form kernel (every stream takes the Cholesky back end)
 };
@@ -2614,16 +2625,23 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
     const bool two_pass = a.over && a.over[s];
     const int n_state = a.stream_n ? a.stream_n[s] : a.base[s].n;
     if (a.work) {        // per gated feature with r = 4M-3 rows against n columns  2 r n^2 + 2 r^2 n + r^3 / 3
-        double fl = 0; int cnt = 0;
+        double fl = 0, fx = 0; int cnt = 0;
         for (int i = i0 + lane; i < i1; i += 64) {
             if (a.valid && !a.valid[i]) continue;
             const double r = 4.0 * (a.obs_off[i + 1] - a.obs_off[i]) - 3.0, n = (double)n_state;
             fl += 2 * r * n * n + 2 * r * r * n + r * r * r / 3.0; ++cnt;
+            // what feature_kernel EXECUTES for a track of M observations (block-sparse: H_x is 4 x 6 per observation, the gate
+            // matrix is built from the M^2 6 x 6 blocks of P before the projection, the reflectors are applied to it from both
+            // sides -- DESIGN.md 3b): Jacobians ~600 M; three reflectors from H_f and the projected residual 96 M; reflectors
+            // over the 6 M columns of H_x (four products per column and reflector, then 4 M rows x 3 updates) 6 M (34 + 24 M);
+            // G = H_x P_sub H_x^T 480 M^2; reflectors on G from both sides 384 M^2; Cholesky r^3 / 3 and the solve r^2
+            const double M = (double)(a.obs_off[i + 1] - a.obs_off[i]);
+            fx += 696 * M + 6 * M * (34 + 24 * M) + 864 * M * M + r * r * r / 3.0 + r * r;
         }
-        fl = wave_sum_f64(fl);
+        fl = wave_sum_f64(fl); fx = wave_sum_f64(fx);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
-        if (lane == 0) { a.work[8 * s] += fl; a.work[8 * s + 3] += (double)cnt; }
+        if (lane == 0) { a.work[8 * s] += fl; a.work[8 * s + 3] += (double)cnt; a.work[8 * s + 6] += fx; }
     }
     int stacked = 0, nb = 0;
     unsigned long long used = 0ull;
@@ -2698,6 +2716,19 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
             a.work[8 * s + 1] += 2 * k * n * n + 2 * k * k * n + k * k * k / 3.0 + 2 * k * k * n + 4 * k * n * n;
             if (mm > n) a.work[8 * s + 2] += 2 * mm * n * n - 2.0 / 3.0 * n * n * n;
             a.work[8 * s + 4] += 1.0; a.work[8 * s + 5] += mm;
+            // what the update kernels EXECUTE over the nc touched columns (analytic, tile padding not counted).  Information form
+            // (nc <= 24): Gram m nc^2, b 2 m nc, A P_cc and the 12 x 12 elimination 4 nc^3, the two products with P[:, c]
+            // 2 n nc^2 + 2 n^2 nc.  Cholesky back end: the Gram compression of a stream with more rows than one pass m (nc + 1)^2 +
+            // (nc + 1)^3 / 3 (then kk = nc rows), T^T 2 n nc kk, S kk^2 nc, Cholesky kk^3 / 3, substitution kk^2 (n + 1),
+            // P - Y^T Y n^2 kk (lower tiles) and delta_x 2 kk n
+            const double c = (double)nc;
+            if (mode == 1) a.work[8 * s + 7] += mm * c * c + 2 * mm * c + 4 * c * c * c + 2 * n * c * c + 2 * n * n * c;
+            else {
+                const bool comp = a.compress && m > a.kch;
+                const double kk = comp ? c : mm;
+                a.work[8 * s + 7] += (comp ? mm * (c + 1) * (c + 1) + (c + 1) * (c + 1) * (c + 1) / 3.0 : 0.0)
+                                     + 2 * n * c * kk + kk * kk * c + kk * kk * kk / 3.0 + kk * kk * (n + 1) + n * n * kk + 2 * kk * n;
+            }
         }
     }
     for (int r = lane; r < a.rounds; r += 64) {
@@ -2734,7 +2765,7 @@ static int msckf_lds_opt_in()
 {
     static const int rc = [] {
         const int lim = 160 * 1024;
-        const void* fns[6] = {reinterpret_cast<const void*>(feature_kernel8),
+        const void* fns[8] = {reinterpret_cast<const void*>(feature_kernel8), reinterpret_cast<const void*>(feature_kernel8_v128), reinterpret_cast<const void*>(upd_info_v128_kernel),
                               reinterpret_cast<const void*>(feature_kernel<16>), reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
                               reinterpret_cast<const void*>(update_front_kernel), reinterpret_cast<const void*>(update_front_batch_kernel)};
         const void* fns2[5] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel),

@@ -469,12 +469,13 @@ int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stri
         const int tx = (w + FT_W - 1) / FT_W, ty = h / FT_H;
         a.n_img = n_img; a.tiles_x = xcd_map ? tx : 0; a.tiles_y = ty;
         dim3 grid = xcd_map ? dim3((unsigned)(tx * ty) * 8u * (unsigned)((n_img + 7) / 8)) : dim3(tx, ty, n_img);
+        static const size_t pad = [] { const char* e = getenv("AV_PYR_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();      // occupancy throttle (A/B), as fast.hip's
         if (FT_H == FT_H_TALL) {
-            if (write_level0) hipLaunchKernelGGL((pyr_l0l1_kernel<true, FT_H_TALL>), grid, dim3(256), 0, st, a);
-            else { hipLaunchKernelGGL((pyr_l0l1_kernel<false, FT_H_TALL>), grid, dim3(256), 0, st, a); if (wrote_level0) *wrote_level0 = false; }
+            if (write_level0) hipLaunchKernelGGL((pyr_l0l1_kernel<true, FT_H_TALL>), grid, dim3(256), pad, st, a);
+            else { hipLaunchKernelGGL((pyr_l0l1_kernel<false, FT_H_TALL>), grid, dim3(256), pad, st, a); if (wrote_level0) *wrote_level0 = false; }
         } else {
-            if (write_level0) hipLaunchKernelGGL((pyr_l0l1_kernel<true, FT_H_BASE>), grid, dim3(256), 0, st, a);
-            else { hipLaunchKernelGGL((pyr_l0l1_kernel<false, FT_H_BASE>), grid, dim3(256), 0, st, a); if (wrote_level0) *wrote_level0 = false; }
+            if (write_level0) hipLaunchKernelGGL((pyr_l0l1_kernel<true, FT_H_BASE>), grid, dim3(256), pad, st, a);
+            else { hipLaunchKernelGGL((pyr_l0l1_kernel<false, FT_H_BASE>), grid, dim3(256), pad, st, a); if (wrote_level0) *wrote_level0 = false; }
         }
         AV_LAUNCH_CHECK();
     } else {

@@ -318,6 +318,14 @@ class BatchedMSCKF(object):
         N.check(N.lib().av_msckf_batch_work(self._h, int(enable), C.byref(o)))
         return dict(zip(self.WORK_NAMES, [float(v) for v in o]))
 
+    def work_executed(self):
+        """fp64 flops the gate / update kernels EXECUTED so far on their block-sparse shapes (av_msckf_batch_work_executed; analytic per
+        gated feature / per update): {'gate_flops_executed', 'update_flops_executed'}.  Drains the queue first."""
+        self.wait(0)
+        o = (C.c_double * 2)()
+        N.check(N.lib().av_msckf_batch_work_executed(self._h, C.byref(o)))
+        return {'gate_flops_executed': float(o[0]), 'update_flops_executed': float(o[1])}
+
     def debug_capture(self, enable=True):
         """Parity-test tap: keep gamma / delta_x / P+ of the two update phases of every stream's last step (tests only)."""
         N.check(N.lib().av_msckf_batch_debug_capture(self._h, 1 if enable else 0))
