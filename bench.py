@@ -69,7 +69,12 @@ LK_TRAFFIC_BYTES_PER_LAUNCH_S64 = (FETCH_SIZE_FACTOR * LK_PMC['fetch_kb'] * LK_P
 LK_VALU_INSTS_PER_LAUNCH_S64 = LK_PMC['valu']
 LK_PMC_POINT_PASSES_PER_STREAM_LAUNCH = 1113.915 / 7.0      # lk_point_passes_per_frame / LK launches per step of the counter runs' workload (grid 4x5x15)
 FP64_PEAK_TFLOPS = 78.6                             # MI355X_MICROARCH.md: fp64 vector = fp64 matrix peak
-VALU_CYCLES_PER_WAVE_INST = 2.0                     # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
+# Issue cost of one VALU wave-instruction of lk_track_g16_kernel's mix at its five waves per SIMD (round 5).  Rounds 2-4 priced every
+# instruction at the guide's 2 cycles (a v_fma_f32); profiles/r05/valu_issue_microbench.json measures the classes apart -- v_add / v_ashr
+# 0.98, v_fma_f32 / v_mul / v_mov 1.6, and 2.55 for what the kernel is made of (v_dot2_i32_i16, its DPP form, v_mad_i32_i16, v_perm_b32,
+# v_alignbyte, packed 16-bit ops, DPP adds, conversions, compares; fp64 the same) -- and a census of the hot path's instructions (4 levels
+# x 510 in the patch set-up + 16.5 iterations x 159: 72.5 % of the 2.55 class, 17.7 % cheap, 9.6 % fp32) averages 2.18.
+VALU_CYCLES_PER_WAVE_INST = 2.18
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
 
 
@@ -726,8 +731,8 @@ def main():
                                                   (timing_fe['lk'][0] / max(timing_fe['lk'][1], 1) * 1e-3)) if timing_fe else None,
                 'note': 'lk_track_g16_kernel is VALU-issue bound (PMC at 64 streams: 21.4 M VALU wave-instructions per launch on the mean over a step\'s launch mix, 38% of wave '
                         'cycles waiting on an instruction, LDS 2% of instructions); its tiles come from L2/Infinity Cache. The HBM fraction is '
-                        'reported because the path class is byte/integer work; valu_issue_frac (2 cycles per wave64 instruction, 1,024 SIMDs at '
-                        '2.4 GHz) is the bound that binds. In the complete path the span also contains the higher-priority filter kernels '
+                        'reported because the path class is byte/integer work; valu_issue_frac (2.18 cycles per wave64 instruction of this kernel\'s mix, measured: '
+                        'profiles/r05/valu_issue_microbench.json and lk_dma_experiment.md; 1,024 SIMDs at 2.4 GHz) is the bound that binds. In the complete path the span also contains the higher-priority filter kernels '
                         'that preempt it.',
                 'avg_launch_ms': lk_avg_ms, 'launches': lk_n, 'algorithmic_bytes_per_launch': lk_bytes_per_launch,
                 # same kernel, same inputs, timed in the front-end-only loop that follows (no filter kernels sharing the GPU)

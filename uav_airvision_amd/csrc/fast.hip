@@ -322,11 +322,9 @@ int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, int bo
     const int tx = (w + TW - 1) / TW, ty = (h + TH - 1) / TH;
     a.n_img = n_img; a.tiles_x = xcd_map ? tx : 0; a.tiles_y = ty; a.index = index;
     dim3 grid = xcd_map ? dim3((unsigned)(tx * ty) * 8u * (unsigned)((n_img + 7) / 8)) : dim3(tx, ty, n_img);
-    // Unused dynamic LDS as an occupancy throttle (AV_FAST_LDS_PAD=bytes per workgroup; A/B): at its natural eight workgroups per CU the
-    // detector holds every wave slot and 152 of the 160 KB of LDS, and a filter kernel queued beside it waits for the whole launch
-    // (profiles/r05/filter_step_contended_timeline_midround.txt: triangulate_kernel 1.57 ms beside fast_kernel, 0.04 ms alone).
-    static const size_t pad = [] { const char* e = getenv("AV_FAST_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
-    hipLaunchKernelGGL(fast_kernel, grid, dim3(256), pad, st, a);
+    // (An occupancy throttle -- unused dynamic LDS holding the detector to 6 / 5 / 4 workgroups per CU so that the filter's kernels find
+    //  room beside it -- was measured in round 5: 156.9 / 154.7 / 149.7 k against 157.5 k frames/s.  profiles/r05/README.md)
+    hipLaunchKernelGGL(fast_kernel, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -643,6 +643,9 @@ __device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, d
     }
     if (a.prof && slot == 0 && tid == 0) a.prof[3] = __builtin_amdgcn_s_memrealtime();
     // rows 3..R4-1 of H and r are A^T H_x and A^T r.  Write them out (dense row of width ld).
+    // (Round 5: rows WITHOUT the zero fill -- three quarters of what a five-observation feature writes are zeros -- and readers that mask
+    //  by the cameras of every stacked block were built, parity-green and measured: 5.87 / 5.91 against 5.97 / 5.87 ms of exclusive chain,
+    //  156.9 / 157.5 against 156.7 / 156.4 k frames/s: within the noise, not kept.  profiles/r05/README.md)
     const int row0 = a.row_off[f];                 // < 0: gate only, nothing is stored (two-pass streams, msckf_batch.inc)
     if (row0 >= 0) {
         if (a.zero_fill) {
@@ -825,10 +828,8 @@ template <> __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bound
 // eight and four lanes per two-observation feature (8 / 16 features per wavefront): the Jacobian phase keeps 2 lanes of a team busy and the
 // gate-matrix blocks 4, whatever the team size -- smaller teams waste fewer lanes there and take more rounds in the later phases
 __global__ __attribute__((amdgpu_waves_per_eu(2, 3))) __launch_bounds__(256) void feature_kernel8(FeatArgs a) { feature_body<8>(a); }
-// A/B (AV_FILTER_V128 bit 0): the same kernel held to 128 registers.  Beside the LK kernel (five waves of 96 registers per SIMD, a deep
-// backlog of workgroups) a 207-register wave needs TWO retiring LK waves of one SIMD that the LK queue does not refill in between; a
-// 128-register wave fits the hole one retiring wave leaves (96 + the 32 spare rows).
-__global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(256) void feature_kernel8_v128(FeatArgs a) { feature_body<8>(a); }
+// (Held to 128 registers -- so that a wave fits the hole ONE retiring LK wave leaves on a SIMD instead of waiting for two -- this kernel
+//  and upd_info_kernel were measured beside the front-end in round 5: 156.0 / 156.9 k against 157.5 k frames/s.  profiles/r05/README.md)
 
 static int msckf_lds_opt_in();       // raises the dynamic-LDS limit of every kernel below once per process
 
@@ -2240,14 +2241,6 @@ __global__ __launch_bounds__(256) void upd_info_kernel(const UpdArgs* __restrict
     if (a.m <= 0 || a.mode != 1) return;
     upd_info_body(a, Li_dyn);
 }
-__global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(256) void upd_info_v128_kernel(const UpdArgs* __restrict__ arr)      // A/B (AV_FILTER_V128 bit 1)
-{
-    AV_FILTER_PRIO();
-    extern __shared__ double Li_dyn[];
-    const UpdArgsG a = upd_load(arr, blockIdx.x);
-    if (a.m <= 0 || a.mode != 1) return;
-    upd_info_body(a, Li_dyn);
-}
 template <typename UA> __device__ __forceinline__ void upd_info_body(const UA& a, double* Li)
 {
     const int tid = threadIdx.x, n = a.n, nc = a.nc, nb = a.n_blk;
@@ -2765,7 +2758,7 @@ static int msckf_lds_opt_in()
 {
     static const int rc = [] {
         const int lim = 160 * 1024;
-        const void* fns[8] = {reinterpret_cast<const void*>(feature_kernel8), reinterpret_cast<const void*>(feature_kernel8_v128), reinterpret_cast<const void*>(upd_info_v128_kernel),
+        const void* fns[6] = {reinterpret_cast<const void*>(feature_kernel8),
                               reinterpret_cast<const void*>(feature_kernel<16>), reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
                               reinterpret_cast<const void*>(update_front_kernel), reinterpret_cast<const void*>(update_front_batch_kernel)};
         const void* fns2[5] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel),

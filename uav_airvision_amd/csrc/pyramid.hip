@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrArgs a, int level)
 // that LDS copy, and both 16-pixel frames are mirrored out of LDS.  The per-level gather kernel spends most of its time in the
 // frame at these sizes (52 % of the padded level 3 is frame, every frame pixel re-filters 25 source bytes through the
 // reflection); here a frame pixel is one LDS byte read.
-constexpr int L23_T = 1024;
+template <int L23_T>
 __global__ __launch_bounds__(L23_T) void pyr_l2l3_kernel(PyrArgs a)
 {
     extern __shared__ uint8_t lds23[];
@@ -469,13 +469,12 @@ int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stri
         const int tx = (w + FT_W - 1) / FT_W, ty = h / FT_H;
         a.n_img = n_img; a.tiles_x = xcd_map ? tx : 0; a.tiles_y = ty;
         dim3 grid = xcd_map ? dim3((unsigned)(tx * ty) * 8u * (unsigned)((n_img + 7) / 8)) : dim3(tx, ty, n_img);
-        static const size_t pad = [] { const char* e = getenv("AV_PYR_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();      // occupancy throttle (A/B), as fast.hip's
         if (FT_H == FT_H_TALL) {
-            if (write_level0) hipLaunchKernelGGL((pyr_l0l1_kernel<true, FT_H_TALL>), grid, dim3(256), pad, st, a);
-            else { hipLaunchKernelGGL((pyr_l0l1_kernel<false, FT_H_TALL>), grid, dim3(256), pad, st, a); if (wrote_level0) *wrote_level0 = false; }
+            if (write_level0) hipLaunchKernelGGL((pyr_l0l1_kernel<true, FT_H_TALL>), grid, dim3(256), 0, st, a);
+            else { hipLaunchKernelGGL((pyr_l0l1_kernel<false, FT_H_TALL>), grid, dim3(256), 0, st, a); if (wrote_level0) *wrote_level0 = false; }
         } else {
-            if (write_level0) hipLaunchKernelGGL((pyr_l0l1_kernel<true, FT_H_BASE>), grid, dim3(256), pad, st, a);
-            else { hipLaunchKernelGGL((pyr_l0l1_kernel<false, FT_H_BASE>), grid, dim3(256), pad, st, a); if (wrote_level0) *wrote_level0 = false; }
+            if (write_level0) hipLaunchKernelGGL((pyr_l0l1_kernel<true, FT_H_BASE>), grid, dim3(256), 0, st, a);
+            else { hipLaunchKernelGGL((pyr_l0l1_kernel<false, FT_H_BASE>), grid, dim3(256), 0, st, a); if (wrote_level0) *wrote_level0 = false; }
         }
         AV_LAUNCH_CHECK();
     } else {
@@ -495,7 +494,9 @@ int av_launch_pyramid(const uint8_t* img0, const uint8_t* img1, int64_t img_stri
             hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, st, a, 1);
             AV_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(pyr_l2l3_kernel, dim3(n_img), dim3(L23_T), lds23, st, a);
+        // (512- and 256-thread workgroups -- a 1,024-thread workgroup is sixteen waves, two of them fill a CU's wave slots -- measured
+        //  0.961 / 0.969 ms of pyramid time per step against 0.973: within the noise, round 5)
+        hipLaunchKernelGGL(pyr_l2l3_kernel<1024>, dim3(n_img), dim3(1024), lds23, st, a);
         AV_LAUNCH_CHECK();
         lbeg = g.levels;
     }
