@@ -269,7 +269,7 @@ __device__ __forceinline__ void jdiff5(uint32_t T0, uint32_t T1, uint32_t T2, ui
 // normal-equation sums.
 template <int WIN, typename LoadRow>
 __device__ __forceinline__ void lk_patch_rows(LoadRow load_row, uint32_t wtop, uint32_t wbot, int ipx, int ipy, int w, int h, int r,
-                                              int (&iv)[WIN], uint32_t (&ixy)[WIN], int& a11, int& a12, int& a22)
+                                              int (&iv)[WIN], uint32_t (&ixx)[(WIN + 1) / 2], uint32_t (&iyy)[(WIN + 1) / 2], int& a11, int& a12, int& a22)
 {
     constexpr int W_BITS = 14;
     a11 = 0; a12 = 0; a22 = 0;
@@ -332,20 +332,25 @@ __device__ __forceinline__ void lk_patch_rows(LoadRow load_row, uint32_t wtop, u
         gyp[2 * k + 1] = mid(gyp[2 * k], gyp[2 * k + 2]);
     }
     const int rnd_i = 1 << (W_BITS - 6), rnd_d = 1 << (W_BITS - 1);      // rounding terms, one register each
+    // The derivative patches are kept as PAIRS of adjacent columns, (Ix[2p] | Ix[2p+1] << 16) and the same for Iy (|Ix|, |Iy| <= 4080;
+    // the 16th column is zero): every window sum is then a chain of v_dot2_i32_i16 -- two columns per instruction -- instead of one
+    // v_mad_i32_i16 per column (24 instead of 45 here, 16 + 7 pair packs instead of 30 in every Newton iteration; the same exact
+    // integers, whatever the grouping).
+    int ixv[WIN + 1], iyv[WIN + 1];
+    ixv[WIN] = 0; iyv[WIN] = 0;
 #pragma unroll
     for (int c = 0; c < WIN; c += 5) {
-        int ix_[5], iy_[5];
         bilin5_seed(px[c], px[c + 1], px[c + 2], px[c + 3], px[c + 4], wtop, wbot, rnd_i, iv[c], iv[c + 1], iv[c + 2], iv[c + 3], iv[c + 4]);
-        bilin5<W_BITS>(gxp[c], gxp[c + 1], gxp[c + 2], gxp[c + 3], gxp[c + 4], wtop, wbot, rnd_d, ix_[0], ix_[1], ix_[2], ix_[3], ix_[4]);
-        bilin5<W_BITS>(gyp[c], gyp[c + 1], gyp[c + 2], gyp[c + 3], gyp[c + 4], wtop, wbot, rnd_d, iy_[0], iy_[1], iy_[2], iy_[3], iy_[4]);
-#pragma unroll
-        for (int u = 0; u < 5; ++u) ixy[c + u] = __builtin_amdgcn_perm((uint32_t)iy_[u], (uint32_t)ix_[u], 0x05040100u);
+        bilin5<W_BITS>(gxp[c], gxp[c + 1], gxp[c + 2], gxp[c + 3], gxp[c + 4], wtop, wbot, rnd_d, ixv[c], ixv[c + 1], ixv[c + 2], ixv[c + 3], ixv[c + 4]);
+        bilin5<W_BITS>(gyp[c], gyp[c + 1], gyp[c + 2], gyp[c + 3], gyp[c + 4], wtop, wbot, rnd_d, iyv[c], iyv[c + 1], iyv[c + 2], iyv[c + 3], iyv[c + 4]);
     }
 #pragma unroll
-    for (int c = 0; c < WIN; ++c) {
-        a11 = mad16<0, 0>(ixy[c], ixy[c], a11);
-        a12 = mad16<0, 1>(ixy[c], ixy[c], a12);
-        a22 = mad16<1, 1>(ixy[c], ixy[c], a22);
+    for (int p = 0; p < (WIN + 1) / 2; ++p) {
+        ixx[p] = __builtin_amdgcn_perm((uint32_t)ixv[2 * p + 1], (uint32_t)ixv[2 * p], 0x05040100u);
+        iyy[p] = __builtin_amdgcn_perm((uint32_t)iyv[2 * p + 1], (uint32_t)iyv[2 * p], 0x05040100u);
+        a11 = dot2(ixx[p], ixx[p], a11);
+        a12 = dot2(ixx[p], iyy[p], a12);
+        a22 = dot2(iyy[p], iyy[p], a22);
     }
     if (r >= WIN) { a11 = 0; a12 = 0; a22 = 0; }
 }
@@ -376,6 +381,14 @@ __device__ __forceinline__ bool lk_track_g16_body(const LKArgs& a)
     const int slot = bx * 16 + g;
     const int sI = a.mapI ? a.mapI[s] : s, sJ = a.mapJ ? a.mapJ[s] : s;      // storage entries of the two images (scalar loads)
     if (sI < 0 || sJ < 0) return false;
+    // Without an index list the point of a slot is known before the set's count is: its loads are issued ahead of the count's (one
+    // dependent memory round trip less at the head of every wavefront; a slot past the count reads a valid entry and leaves)
+    const bool direct = a.index == nullptr && slot < a.cap;
+    float prevx0 = 0.f, prevy0 = 0.f, curx = 0.f, cury = 0.f;
+    if (direct) {
+        const size_t p0 = (size_t)s * a.cap + slot;
+        prevx0 = a.prev[2 * p0]; prevy0 = a.prev[2 * p0 + 1]; curx = a.next[2 * p0]; cury = a.next[2 * p0 + 1];
+    }
     const int n = min(a.count[s], a.cap);
     if (slot >= n) return false;                    // uniform per 16-lane group
     const int pidx = a.index ? a.index[(size_t)s * a.cap + slot] : slot;
@@ -383,8 +396,7 @@ __device__ __forceinline__ bool lk_track_g16_body(const LKArgs& a)
     const uint8_t* PI = a.pyrI + sI * a.stream_stride;
     const uint8_t* PJ = a.pyrJ + sJ * a.stream_stride;
     const size_t pi = (size_t)s * a.cap + pidx;
-    const float prevx0 = a.prev[2 * pi], prevy0 = a.prev[2 * pi + 1];
-    float curx = a.next[2 * pi], cury = a.next[2 * pi + 1];
+    if (!direct) { prevx0 = a.prev[2 * pi]; prevy0 = a.prev[2 * pi + 1]; curx = a.next[2 * pi]; cury = a.next[2 * pi + 1]; }
     const float halfWin = (WIN - 1) * 0.5f;
     const bool rowact = r < WIN;
     bool ok = true;
@@ -460,13 +472,13 @@ __device__ __forceinline__ bool lk_track_g16_body(const LKArgs& a)
 
         // ---- this lane's row of the I patch and of the Scharr patches: staged rows r..r+2, 18 bytes of each -------------
         int iv[WIN];
-        uint32_t ixy[WIN];                        // (Ix | Iy << 16) per window column
+        uint32_t ixx[(WIN + 1) / 2], iyy[(WIN + 1) / 2];      // (Ix[2p] | Ix[2p+1] << 16), the same for Iy: pairs of window columns
         int a11, a12, a22;
         lk_patch_rows<WIN>([&](int t, uint32_t (&B)[5]) {
                                const uint32_t* rowp = tile + __mul24(r + t, TPITCH / 4);
 #pragma unroll
                                for (int k = 0; k < 5; ++k) B[k] = rowp[k];
-                           }, wtop, wbot, ipx, ipy, w, h, r, iv, ixy, a11, a12, a22);
+                           }, wtop, wbot, ipx, ipy, w, h, r, iv, ixx, iyy, a11, a12, a22);
         const float A11 = row_sum16_scaled(a11);
         const float A12 = row_sum16_scaled(a12);
         const float A22 = row_sum16_scaled(a22);
@@ -544,9 +556,11 @@ __device__ __forceinline__ bool lk_track_g16_body(const LKArgs& a)
             jdiff5<10>(T0, T1, T2, T3, sel0, sel1, sel2, sel3, wtop, wbot, iv[10], iv[11], iv[12], iv[13], iv[14], df[10], df[11], df[12], df[13], df[14]);
             int b1 = 0, b2 = 0;
 #pragma unroll
-            for (int c = 0; c < WIN; ++c) {
-                b1 = mad16<0, 0>((uint32_t)df[c], ixy[c], b1);
-                b2 = mad16<0, 1>((uint32_t)df[c], ixy[c], b2);
+            for (int p = 0; p < (WIN + 1) / 2; ++p) {
+                // (|J - I| <= 8160 fits 16 bits; the high half of the last pair multiplies the zero 16th column: df[14] goes in as it is)
+                const uint32_t dp = 2 * p + 1 < WIN ? __builtin_amdgcn_perm((uint32_t)df[2 * p + 1 < WIN ? 2 * p + 1 : 0], (uint32_t)df[2 * p], 0x05040100u) : (uint32_t)df[2 * p];
+                b1 = dot2(dp, ixx[p], b1);
+                b2 = dot2(dp, iyy[p], b2);
             }
             if (!rowact) { b1 = 0; b2 = 0; }
             const float fb1 = row_sum16_scaled(b1);
