@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 W_IMG, H_IMG = 752, 480
 LK_BYTES_PER_POINT_PASS = 4 * 2 * 289 + 25          # L=4 levels x (I + J window of 17x17) + point I/O
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/s spec
-# rocprofv3 PMC passes of `bench.py --frontend-only --streams 64` (three separate passes: SQ block, FETCH_SIZE, WRITE_SIZE; collected
+# rocprofv3 PMC passes of `bench.py --frontend-only --streams 64|512` (three separate passes: SQ block, FETCH_SIZE, WRITE_SIZE; collected
 # by profiles/r03/collect_pmc.sh, per-kernel means in the committed summary read below).  Per lk_track_g16_kernel launch, mean over
 # the launch mix of a step (temporal, stereo forward / backward of the tracked points: 300 point passes per stream each; candidates
 # round 1 forward / backward: 100 each; round 2: ~10 each), 64 streams per launch; bench.py's avg_launch_ms is the mean over the same
@@ -44,6 +44,14 @@ HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/
 # every case, and a sparse read costs the time of the whole line (a request is 128 B, tallied as 64) -- so the x2 applies to this
 # kernel's 4-byte staging loads as well (round 2 argued it might not; it does).  WRITE_SIZE is exact.
 def _load_pmc():
+    # round 5: all three counter families measured at 512 streams per launch with the round's kernel (profiles/r05/final_pmc.sh: the
+    # largest batch rocprofv3 --pmc collects on this image), the 64-stream pass beside it for the per-stream scaling check
+    p512 = os.path.join(ROOT, 'profiles', 'r05', 'pmc_frontend_s512_summary.json')
+    if os.path.exists(p512):
+        e = json.load(open(p512))['lk_track_g16_kernel<15>']
+        return dict(path=os.path.relpath(p512, ROOT), streams=512, fetch_kb=float(e['FETCH_SIZE']), write_kb=float(e['WRITE_SIZE']),
+                    valu=float(e['SQ_INSTS_VALU']), waves=float(e['SQ_WAVES']), fetch_streams=512, fetch_path=os.path.relpath(p512, ROOT),
+                    wait_inst_share=float(e['wait_inst_share']), wait_any_share=float(e['wait_any_share']))
     for d in ('r03', 'r02'):
         path = os.path.join(ROOT, 'profiles', d, 'pmc_frontend_s64_summary.json')
         if os.path.exists(path):

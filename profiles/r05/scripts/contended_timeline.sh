@@ -1,6 +1,6 @@
 #!/bin/bash
 set -o pipefail
-O=$PWD/gpurun_out/r05d; mkdir -p $O
+O=$PWD/gpurun_out/r05y; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/t4

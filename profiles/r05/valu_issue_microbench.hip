@@ -73,6 +73,24 @@
 #define OP_MOV(d)          "v_mov_b32 v" S(d) ", v2\n\t"
 #define OP_SNOP(d)         "s_nop 0\n\t"
 #define OP_CMP_F32(d)      "v_cmp_lt_f32 vcc, v6, v7\n\t"
+#define OP_MIN_I32(d)      "v_min_i32 v" S(d) ", v2, v3\n\t"
+#define OP_MAX_U32(d)      "v_max_u32 v" S(d) ", v2, v3\n\t"
+#define OP_BFE_U32(d)      "v_bfe_u32 v" S(d) ", v2, 8, 8\n\t"
+#define OP_LSHL_OR(d)      "v_lshl_or_b32 v" S(d) ", v2, 16, v3\n\t"
+#define OP_AND_OR(d)       "v_and_or_b32 v" S(d) ", v2, v3, v4\n\t"
+#define OP_ADD3(d)         "v_add3_u32 v" S(d) ", v2, v3, v4\n\t"
+#define OP_BFI(d)          "v_bfi_b32 v" S(d) ", v2, v3, v4\n\t"
+#define OP_ALIGNBIT(d)     "v_alignbit_b32 v" S(d) ", v2, v3, 9\n\t"
+#define OP_SUB_SDWA(d)     "v_sub_u32_sdwa v" S(d) ", v2, v3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"
+#define OP_PK_MIN_I16(d)   "v_pk_min_i16 v" S(d) ", v2, v3\n\t"
+#define OP_PK_SUB_I16(d)   "v_pk_sub_i16 v" S(d) ", v2, v3\n\t"
+#define OP_PK_MAD_U16(d)   "v_pk_mad_u16 v" S(d) ", v2, v3, v4\n\t"
+#define OP_CMP_GT_I32(d)   "v_cmp_gt_i32 vcc, v2, v3\n\t"
+#define OP_CNDMASK_E64(d)  "v_cndmask_b32_e64 v" S(d) ", v2, v3, s[22:23]\n\t"
+#define OP_MUL_U24(d)      "v_mul_u32_u24 v" S(d) ", v2, v3\n\t"
+#define OP_MOV_DPP(d)      "v_mov_b32_dpp v" S(d) ", v2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define OP_DOT4_U8(d)      "v_dot4_u32_u8 v" S(d) ", v2, v3, v4\n\t"
+#define OP_MAD_U32_U24(d)  "v_mad_u32_u24 v" S(d) ", v2, v3, v4\n\t"
 #define OP_DS_READ(d)      "ds_read_b32 v" S(d) ", v5\n\ts_waitcnt lgkmcnt(8)\n\t"
 // chains: every instruction reads the previous result
 #define CH_FMA_F32(d)      "v_fma_f32 v8, v8, v3, v4\n\t"
@@ -99,9 +117,9 @@
 
 #define PROLOGUE                                                                                                        \
     asm volatile("v_mov_b32 v2, %0\n\tv_mov_b32 v3, %1\n\tv_mov_b32 v4, %2\n\tv_and_b32 v5, 0xfc, %0\n\t"               \
-                 "v_cvt_f32_u32 v6, %0\n\tv_cvt_f32_u32 v7, %1\n\ts_mov_b32 s20, 0x0c010c00\n\t"                        \
+                 "v_cvt_f32_u32 v6, %0\n\tv_cvt_f32_u32 v7, %1\n\ts_mov_b32 s20, 0x0c010c00\n\ts_mov_b64 s[22:23], 0x5555\n\t"                        \
                  "v_cvt_f64_u32 v[42:43], %0\n\tv_cvt_f64_u32 v[44:45], %1\n\tv_cvt_f64_u32 v[46:47], %2\n\tv_mov_b32 v8, %0\n\tv_mov_b32 v9, 0\n\t" \
-                 ::"v"(x), "v"(y), "v"(z) : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v42", "v43", "v44", "v45", "v46", "v47", "s20")
+                 ::"v"(x), "v"(y), "v"(z) : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v42", "v43", "v44", "v45", "v46", "v47", "s20", "s22", "s23")
 
 #define KERNEL(NAME, BLOCK)                                                                             \
     __global__ __launch_bounds__(256) void k_##NAME(uint64_t* out, int n, int seed)                     \
@@ -152,6 +170,24 @@ KERNEL(cndmask_b32, BLK32_IND(OP_CNDMASK))
 KERNEL(mov_b32, BLK32_IND(OP_MOV))
 KERNEL(s_nop, BLK32_IND(OP_SNOP))
 KERNEL(cmp_lt_f32, BLK32_IND(OP_CMP_F32))
+KERNEL(min_i32, BLK32_IND(OP_MIN_I32))
+KERNEL(max_u32, BLK32_IND(OP_MAX_U32))
+KERNEL(bfe_u32, BLK32_IND(OP_BFE_U32))
+KERNEL(lshl_or_b32, BLK32_IND(OP_LSHL_OR))
+KERNEL(and_or_b32, BLK32_IND(OP_AND_OR))
+KERNEL(add3_u32, BLK32_IND(OP_ADD3))
+KERNEL(bfi_b32, BLK32_IND(OP_BFI))
+KERNEL(alignbit_b32, BLK32_IND(OP_ALIGNBIT))
+KERNEL(sub_u32_sdwa_bytes, BLK32_IND(OP_SUB_SDWA))
+KERNEL(pk_min_i16, BLK32_IND(OP_PK_MIN_I16))
+KERNEL(pk_sub_i16, BLK32_IND(OP_PK_SUB_I16))
+KERNEL(pk_mad_u16, BLK32_IND(OP_PK_MAD_U16))
+KERNEL(cmp_gt_i32, BLK32_IND(OP_CMP_GT_I32))
+KERNEL(cndmask_b32_sgpr_mask, BLK32_IND(OP_CNDMASK_E64))
+KERNEL(mul_u32_u24, BLK32_IND(OP_MUL_U24))
+KERNEL(mov_b32_dpp, BLK32_IND(OP_MOV_DPP))
+KERNEL(dot4_u32_u8, BLK32_IND(OP_DOT4_U8))
+KERNEL(mad_u32_u24, BLK32_IND(OP_MAD_U32_U24))
 KERNEL(ds_read_b32, BLK32_IND(OP_DS_READ))
 KERNEL(chain_fma_f32, BLK32_IND(CH_FMA_F32))
 KERNEL(chain_add_u32, BLK32_IND(CH_ADD_U32))
@@ -180,7 +216,9 @@ static const Entry entries[] = {
     E(fma_f32), E(add_u32), E(ashrrev_i32), E(and_b32_literal), E(dot2_i32_i16), E(dot2c_i32_i16_dpp), E(dot2c_i32_i16), E(mad_i32_i16),
     E(mad_i32_i16_opsel), E(mad_i32_i24), E(perm_b32), E(alignbyte_b32), E(pk_add_u16), E(pk_mul_lo_u16), E(add_u32_dpp_quad),
     E(add_u32_dpp_row_mirror), E(cvt_f32_i32), E(cvt_i32_f32), E(rndne_f32), E(floor_f32), E(mul_f32), E(sqrt_f32), E(rcp_f32),
-    E(cndmask_b32), E(mov_b32), E(s_nop), E(cmp_lt_f32), E(ds_read_b32),
+    E(cndmask_b32), E(mov_b32), E(s_nop), E(cmp_lt_f32), E(min_i32), E(max_u32), E(bfe_u32), E(lshl_or_b32), E(and_or_b32), E(add3_u32), E(bfi_b32),
+    E(alignbit_b32), E(sub_u32_sdwa_bytes), E(pk_min_i16), E(pk_sub_i16), E(pk_mad_u16), E(cmp_gt_i32), E(cndmask_b32_sgpr_mask), E(mul_u32_u24),
+    E(mov_b32_dpp), E(dot4_u32_u8), E(mad_u32_u24), E(ds_read_b32),
     E(chain_fma_f32), E(chain_add_u32), E(chain_dot2_i32_i16), E(chain_dot2c_dpp), E(chain_mad_i32_i16), E(chain_mad_i32_i16_opsel),
     E(chain_mad_i32_i24), E(chain_perm_b32), E(chain_add_u32_dpp_snop1), E(chain_ashrrev),
     E(cvt_f64_i32), E(cvt_f64_f32), E(cvt_f32_f64), E(ldexp_f64), E(add_f64), E(mul_f64), E(fma_f64), E(cmp_lt_f64), E(chain_fma_f64), E(chain_add_f64)};

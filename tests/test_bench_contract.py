@@ -45,15 +45,21 @@ def test_pmc_constants_come_from_the_committed_summary():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     path = os.path.join(ROOT, bench.LK_PMC['path'])
-    e = json.load(open(path))['lk_track_g16_kernel<15>']
-    assert bench.LK_PMC['write_kb'] == e['WRITE_SIZE'] and bench.LK_PMC['valu'] == e['SQ_INSTS_VALU']
-    # round 4: FETCH_SIZE comes from the largest batch rocprofv3 --pmc could collect (profiles/r04/pmc_fetch_scaling.json), scaled to 64 streams
+    e5 = json.load(open(path))['lk_track_g16_kernel<15>']
+    # round 5: every counter family at 512 streams per launch, with the round's kernel (profiles/r05/pmc_frontend_s512_summary.json)
+    assert bench.LK_PMC['path'] == os.path.join('profiles', 'r05', 'pmc_frontend_s512_summary.json')
+    assert bench.LK_PMC['write_kb'] == e5['WRITE_SIZE'] and bench.LK_PMC['valu'] == e5['SQ_INSTS_VALU'] and bench.LK_PMC['fetch_kb'] == e5['FETCH_SIZE']
+    assert bench.LK_PMC['streams'] == bench.LK_PMC['fetch_streams'] == 512
+    assert abs(bench.LK_TRAFFIC_BYTES_PER_LAUNCH_S64 - (bench.FETCH_SIZE_FACTOR * e5['FETCH_SIZE'] + e5['WRITE_SIZE']) * 1024) < 1e-6
+    e64 = json.load(open(os.path.join(ROOT, 'profiles', 'r05', 'pmc_frontend_s64_summary.json')))['lk_track_g16_kernel<15>']
+    for c in ('FETCH_SIZE', 'SQ_INSTS_VALU'):                 # per-stream figures move by < 6 % between 64 and 512 streams: linear scaling holds
+        assert abs((e5[c] / 512) / (e64[c] / 64) - 1.0) < 0.06, c
+    # rounds 3 / 4: the committed lines of those rounds carry the constants of their own summaries
+    e = json.load(open(os.path.join(ROOT, 'profiles', 'r03', 'pmc_frontend_s64_summary.json')))['lk_track_g16_kernel<15>']
     sc = json.load(open(os.path.join(ROOT, 'profiles', 'r04', 'pmc_fetch_scaling.json')))
     big = max(sc['streams'], key=int)
     f_big = sc['streams'][big]['lk_track_g16_kernel<15>']['FETCH_SIZE_KB_mean']
-    assert bench.LK_PMC['fetch_kb'] == f_big and bench.LK_PMC['fetch_streams'] == int(big) >= 512
-    assert abs(bench.LK_TRAFFIC_BYTES_PER_LAUNCH_S64 - (bench.FETCH_SIZE_FACTOR * f_big * 64 / int(big) + e['WRITE_SIZE']) * 1024) < 1e-6
-    per = sc['lk_fetch_kb_per_stream']                        # the per-stream figure moves by < 5 % between 64 and 512 streams: linear scaling holds
+    per = sc['lk_fetch_kb_per_stream']
     assert abs(per[big] / per['64'] - 1.0) < 0.05
     calib = json.load(open(os.path.join(ROOT, 'profiles', 'r03', 'fetch_calib.json')))['kernels']
     for k in ('read16', 'read4', 'read1'):                      # the measured factor: FETCH_SIZE reports half of the bytes, whatever the lane width
@@ -62,7 +68,7 @@ def test_pmc_constants_come_from_the_committed_summary():
     lines = [f for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r03', 'bench_*.json'))) if 'under_rocprof' not in f]
     for f in lines:
         d = json.loads(open(f).read().strip().splitlines()[-1])
-        if 'pmc_constants' in d and d['pmc_constants']['path'] == bench.LK_PMC['path']:
+        if 'pmc_constants' in d and d['pmc_constants']['path'] == os.path.join('profiles', 'r03', 'pmc_frontend_s64_summary.json'):
             assert d['pmc_constants']['fetch_kb'] == e['FETCH_SIZE'] and d['pmc_constants']['valu'] == e['SQ_INSTS_VALU'], f
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r04', 'bench_*.json'))):
         if 'under_rocprof' in f:
@@ -70,3 +76,7 @@ def test_pmc_constants_come_from_the_committed_summary():
         d = json.loads(open(f).read().strip().splitlines()[-1])
         if 'pmc_constants' in d:
             assert d['pmc_constants']['fetch_kb'] == f_big and d['pmc_constants']['valu'] == e['SQ_INSTS_VALU'], f
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r05', 'bench_*_r05.json'))):
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        if 'pmc_constants' in d:
+            assert d['pmc_constants']['fetch_kb'] == e5['FETCH_SIZE'] and d['pmc_constants']['valu'] == e5['SQ_INSTS_VALU'], f

@@ -186,18 +186,19 @@ __device__ __forceinline__ void bilin5_seed(uint32_t x0, uint32_t x1, uint32_t x
         "v_dot2c_i32_i16_dpp %2, %7, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_dot2c_i32_i16_dpp %3, %8, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_dot2c_i32_i16_dpp %4, %9, %11 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-        "v_and_b32 %0, 0xfffffe00, %0\n\t"
-        "v_and_b32 %1, 0xfffffe00, %1\n\t"
-        "v_and_b32 %2, 0xfffffe00, %2\n\t"
-        "v_and_b32 %3, 0xfffffe00, %3\n\t"
-        "v_and_b32 %4, 0xfffffe00, %4\n\t"
-        "v_sub_u32 %0, 0x100, %0\n\t"
-        "v_sub_u32 %1, 0x100, %1\n\t"
-        "v_sub_u32 %2, 0x100, %2\n\t"
-        "v_sub_u32 %3, 0x100, %3\n\t"
-        "v_sub_u32 %4, 0x100, %4"
+        "v_and_b32 %0, %13, %0\n\t"
+        "v_and_b32 %1, %13, %1\n\t"
+        "v_and_b32 %2, %13, %2\n\t"
+        "v_and_b32 %3, %13, %3\n\t"
+        "v_and_b32 %4, %13, %4\n\t"
+        "v_sub_u32 %0, %14, %0\n\t"
+        "v_sub_u32 %1, %14, %1\n\t"
+        "v_sub_u32 %2, %14, %2\n\t"
+        "v_sub_u32 %3, %14, %3\n\t"
+        "v_sub_u32 %4, %14, %4"
         : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4)
-        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(wtop), "v"(wbot), "v"(rnd));
+        // (the two constants in scalar registers: with a 32-bit literal v_and / v_sub cost 1.6 issue cycles instead of 1.0 -- valu_issue_microbench.json)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(wtop), "v"(wbot), "v"(rnd), "s"(0xfffffe00u), "s"(0x100u));
 }
 
 // a * b + c on the low 24 bits of a and b, ONE instruction (left to itself the compiler turns `c += __mul24(a, b)` chains into
