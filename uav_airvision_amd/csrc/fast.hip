@@ -58,40 +58,53 @@ struct FastArgs {
 // (j, j + 8) is the pair (j + 1, j + 9), and past the end of the array it is an earlier pair with its halves swapped, which
 // the packed instructions take for free through their operand half selects.
 typedef short av_s2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ av_s2 s2_swap(av_s2 x) { return __builtin_shufflevector(x, x, 1, 0); }
-__device__ __forceinline__ av_s2 s2_min(av_s2 a, av_s2 b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ av_s2 s2_max(av_s2 a, av_s2 b) { return __builtin_elementwise_max(a, b); }
+// Three-input packed minima / maxima (round 5).  gfx950 has no three-input packed INTEGER min / max, but it has v_pk_minimum3_f16 /
+// v_pk_maximum3_f16, and the order of non-negative half-precision bit patterns is the order of the integers they spell: the ring
+// differences are biased into 1 .. 511 (subnormal patterns, kept as they are: the kernel runs with fp16 denormals on, the default),
+// compared as halves, and un-biased at the end.  A window minimum of nine = min3(min4, min4, far) is then ONE instruction instead of
+// two, and two windows fold into the running best at once: 56 packed operations per candidate instead of 80 (every one of them costs
+// 2.55 issue cycles, profiles/r05/valu_issue_microbench.json).  Same integers, same scores: tests/test_gpu_ops.py.
+typedef _Float16 av_h2 __attribute__((ext_vector_type(2)));
+typedef unsigned short av_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ av_h2 h2_swap(av_h2 x) { return __builtin_shufflevector(x, x, 1, 0); }
+__device__ __forceinline__ av_h2 h2_min(av_h2 a, av_h2 b) { return __builtin_elementwise_minimum(a, b); }
+__device__ __forceinline__ av_h2 h2_max(av_h2 a, av_h2 b) { return __builtin_elementwise_maximum(a, b); }
+__device__ __forceinline__ av_h2 h2_min3(av_h2 a, av_h2 b, av_h2 c) { return __builtin_elementwise_minimum(__builtin_elementwise_minimum(a, b), c); }
+__device__ __forceinline__ av_h2 h2_max3(av_h2 a, av_h2 b, av_h2 c) { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); }
 __device__ __forceinline__ int fast_score(const uint8_t* c, int t)
 {
     // c points at the centre pixel inside the LDS pixel tile (row stride PW)
     constexpr int DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     constexpr int DY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    constexpr int BIAS = 256;
     const int v = c[0];
-    const av_s2 v2 = {(short)v, (short)v};
-    av_s2 D[8];                                     // d[j] = v - ring[j], d[j + 8]
+    const av_us2 vb = {(unsigned short)(v + BIAS), (unsigned short)(v + BIAS)};
+    av_h2 D[8];                                     // BIAS + v - ring[j], BIAS + v - ring[j + 8]: 1 .. 511
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint32_t pk = (uint32_t)c[DY[j] * PW + DX[j]] | ((uint32_t)c[DY[j + 8] * PW + DX[j + 8]] << 16);
-        D[j] = v2 - __builtin_bit_cast(av_s2, pk);
+        D[j] = __builtin_bit_cast(av_h2, vb - __builtin_bit_cast(av_us2, pk));
     }
-    av_s2 L2[8], H2[8], L4[8], H4[8];               // min / max over 2 and over 4 consecutive ring positions
+    av_h2 L2[8], H2[8], L4[8], H4[8];               // min / max over 2 and over 4 consecutive ring positions
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const av_s2 nx = j < 7 ? D[j + 1] : s2_swap(D[0]); L2[j] = s2_min(D[j], nx); H2[j] = s2_max(D[j], nx); }
+    for (int j = 0; j < 8; ++j) { const av_h2 nx = j < 7 ? D[j + 1] : h2_swap(D[0]); L2[j] = h2_min(D[j], nx); H2[j] = h2_max(D[j], nx); }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        L4[j] = s2_min(L2[j], j < 6 ? L2[j + 2] : s2_swap(L2[j - 6]));
-        H4[j] = s2_max(H2[j], j < 6 ? H2[j + 2] : s2_swap(H2[j - 6]));
+        L4[j] = h2_min(L2[j], j < 6 ? L2[j + 2] : h2_swap(L2[j - 6]));
+        H4[j] = h2_max(H2[j], j < 6 ? H2[j + 2] : h2_swap(H2[j - 6]));
     }
-    av_s2 A = {-256, -256}, Bm = {256, 256};
+    av_h2 lo9[8], hi9[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {                   // windows of 9: positions i..i+3, i+4..i+7, i+8
-        const av_s2 far = s2_swap(D[j]);
-        const av_s2 lo9 = s2_min(s2_min(L4[j], j < 4 ? L4[j + 4] : s2_swap(L4[j - 4])), far);
-        const av_s2 hi9 = s2_max(s2_max(H4[j], j < 4 ? H4[j + 4] : s2_swap(H4[j - 4])), far);
-        A = s2_max(A, lo9);         // best arc of "centre brighter than ring by at least"
-        Bm = s2_min(Bm, hi9);       // best arc of "centre darker than ring by at least" (negated)
+        const av_h2 far = h2_swap(D[j]);
+        lo9[j] = h2_min3(L4[j], j < 4 ? L4[j + 4] : h2_swap(L4[j - 4]), far);
+        hi9[j] = h2_max3(H4[j], j < 4 ? H4[j + 4] : h2_swap(H4[j - 4]), far);
     }
-    const int m = max(max((int)A.x, (int)A.y), -min((int)Bm.x, (int)Bm.y));
+    av_h2 A = h2_max(lo9[0], lo9[1]), Bm = h2_min(hi9[0], hi9[1]);      // best arc of "centre brighter than ring by at least" / "darker" (negated)
+#pragma unroll
+    for (int j = 2; j < 8; j += 2) { A = h2_max3(A, lo9[j], lo9[j + 1]); Bm = h2_min3(Bm, hi9[j], hi9[j + 1]); }
+    const av_us2 Au = __builtin_bit_cast(av_us2, A), Bu = __builtin_bit_cast(av_us2, Bm);
+    const int m = max(max((int)Au.x, (int)Au.y) - BIAS, BIAS - min((int)Bu.x, (int)Bu.y));
     return m > t ? m - 1 : 0;
 }
 
@@ -255,11 +268,10 @@ __global__ __launch_bounds__(256) void fast_kernel(FastArgs a)
         typedef unsigned short av_u2 __attribute__((ext_vector_type(2)));
         auto pair = [&](int d, uint32_t sel) -> av_u2 { return __builtin_bit_cast(av_u2, __builtin_amdgcn_perm(hi[d], lo[d], sel)); };
         constexpr uint32_t P01 = 0x0C010C00u, P12 = 0x0C020C01u, P23 = 0x0C030C02u, P34 = 0x0C040C03u, P45 = 0x0C050C04u;
-        auto mx3 = [](av_u2 x, av_u2 y, av_u2 z) -> av_u2 { return __builtin_elementwise_max(__builtin_elementwise_max(x, y), z); };
-        const av_u2 n01 = __builtin_elementwise_max(mx3(mx3(pair(0, P01), pair(0, P12), pair(0, P23)), pair(1, P01), pair(1, P23)),
-                                                    mx3(pair(2, P01), pair(2, P12), pair(2, P23)));
-        const av_u2 n23 = __builtin_elementwise_max(mx3(mx3(pair(0, P23), pair(0, P34), pair(0, P45)), pair(1, P23), pair(1, P45)),
-                                                    mx3(pair(2, P23), pair(2, P34), pair(2, P45)));
+        // (scores are 0 .. 254: as half-precision bit patterns they order like the integers -- one v_pk_maximum3_f16 per three, see fast_score)
+        auto mx3 = [](av_u2 x, av_u2 y, av_u2 z) -> av_u2 { return __builtin_bit_cast(av_u2, h2_max3(__builtin_bit_cast(av_h2, x), __builtin_bit_cast(av_h2, y), __builtin_bit_cast(av_h2, z))); };
+        const av_u2 n01 = mx3(mx3(pair(0, P01), pair(0, P12), pair(0, P23)), mx3(pair(2, P01), pair(2, P12), pair(2, P23)), mx3(pair(1, P01), pair(1, P23), pair(1, P23)));
+        const av_u2 n23 = mx3(mx3(pair(0, P23), pair(0, P34), pair(0, P45)), mx3(pair(2, P23), pair(2, P34), pair(2, P45)), mx3(pair(1, P23), pair(1, P45), pair(1, P45)));
         const av_u2 g01 = __builtin_elementwise_sub_sat(pair(1, P12), n01), g23 = __builtin_elementwise_sub_sat(pair(1, P34), n23);
         const uint32_t gt[2] = {__builtin_bit_cast(uint32_t, g01), __builtin_bit_cast(uint32_t, g23)};      // half k & 1 of gt[k >> 1] != 0: score > all 8 neighbours
 #pragma unroll
