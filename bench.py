@@ -77,12 +77,15 @@ LK_TRAFFIC_BYTES_PER_LAUNCH_S64 = (FETCH_SIZE_FACTOR * LK_PMC['fetch_kb'] * LK_P
 LK_VALU_INSTS_PER_LAUNCH_S64 = LK_PMC['valu']
 LK_PMC_POINT_PASSES_PER_STREAM_LAUNCH = 1113.915 / 7.0      # lk_point_passes_per_frame / LK launches per step of the counter runs' workload (grid 4x5x15)
 FP64_PEAK_TFLOPS = 78.6                             # MI355X_MICROARCH.md: fp64 vector = fp64 matrix peak
-# Issue cost of one VALU wave-instruction of lk_track_g16_kernel's mix at its five waves per SIMD (round 5).  Rounds 2-4 priced every
-# instruction at the guide's 2 cycles (a v_fma_f32); profiles/r05/valu_issue_microbench.json measures the classes apart -- v_add / v_ashr
-# 0.98, v_fma_f32 / v_mul / v_mov 1.6, and 2.55 for what the kernel is made of (v_dot2_i32_i16, its DPP form, v_mad_i32_i16, v_perm_b32,
-# v_alignbyte, packed 16-bit ops, DPP adds, conversions, compares; fp64 the same) -- and a census of the hot path's instructions (4 levels
-# x 510 in the patch set-up + 16.5 iterations x 159: 72.5 % of the 2.55 class, 17.7 % cheap, 9.6 % fp32) averages 2.18.
-VALU_CYCLES_PER_WAVE_INST = 2.18
+# Issue cost of one VALU wave-instruction of lk_track_g16_kernel's mix (round 5).  Rounds 2-4 priced every instruction at the guide's
+# 2 cycles (a v_fma_f32).  profiles/r05/valu_issue_microbench.json times ~65 instructions apart (wall clock of whole launches, one
+# workgroup per CU, 1-4 waves per SIMD; cross-check: v_fma_f64 comes out at 61 TFLOP/s chip-wide, round 2 measured 60): there are two
+# classes -- FULL rate (v_add_u32, shifts, v_and, v_fma_f32, v_mul_f32, v_mov: 1.24 ns per wave-instruction and SIMD) and HALF rate
+# (v_dot2_i32_i16 and its DPP form, v_mad_i32_i16 / _i24, v_perm, v_alignbyte, packed 16-bit, DPP, SDWA, min / max, bfe, every
+# three-operand integer op, conversions, compares, all of fp64: 2.07 ns = 1.66x) -- and a census of the kernel's hot path finds 70.3 %
+# of its instructions in the half-rate class (lk_dma_experiment.md).  The guide's 2 cycles x (0.703 x 1.66 + 0.297) = 2.93.
+# SQ_INSTS_VALU itself is exact (valu_counter_calib.txt: 64,022 per wave for every class against 64,000 + prologue executed).
+VALU_CYCLES_PER_WAVE_INST = 2.93
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
 
 
@@ -739,7 +742,7 @@ def main():
                                                   (timing_fe['lk'][0] / max(timing_fe['lk'][1], 1) * 1e-3)) if timing_fe else None,
                 'note': 'lk_track_g16_kernel is VALU-issue bound (PMC at 64 streams: 21.4 M VALU wave-instructions per launch on the mean over a step\'s launch mix, 38% of wave '
                         'cycles waiting on an instruction, LDS 2% of instructions); its tiles come from L2/Infinity Cache. The HBM fraction is '
-                        'reported because the path class is byte/integer work; valu_issue_frac (2.18 cycles per wave64 instruction of this kernel\'s mix, measured: '
+                        'reported because the path class is byte/integer work; valu_issue_frac (2.93 cycles per wave64 instruction of this kernel\'s mix = the guide\'s 2 x the measured relative price of its half-rate instructions: '
                         'profiles/r05/valu_issue_microbench.json and lk_dma_experiment.md; 1,024 SIMDs at 2.4 GHz) is the bound that binds. In the complete path the span also contains the higher-priority filter kernels '
                         'that preempt it.',
                 'avg_launch_ms': lk_avg_ms, 'launches': lk_n, 'algorithmic_bytes_per_launch': lk_bytes_per_launch,

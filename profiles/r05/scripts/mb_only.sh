@@ -4,5 +4,5 @@ O=$PWD/gpurun_out/r05n; mkdir -p $O
 python3 - $O/valu_issue_microbench.json <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))
-for r in d['rows']: print("%-28s w1 %6.2f  w2 %6.2f  w4 %6.2f  w5 %6.2f" % (r["op"], r["w1"], r["w2"], r["w4"], r["w5"]))
+for r in d['rows']: print("%-28s w1 %6.2f  w2 %6.2f  w3 %6.2f  w4 %6.2f  w4_ns %s  launch/loop %s" % (r["op"], r["w1"], r["w2"], r["w3"], r["w4"], r.get("w4_ns"), r.get("launch_over_loop")))
 PY

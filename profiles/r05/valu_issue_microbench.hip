@@ -8,9 +8,10 @@
 // N x 32 instances of ONE instruction (32 independent destinations, or one dependent chain), s_memtime around the loop;
 // cycles per wave-instruction and SIMD = (t1 - t0) / (N * 32 * W) with all W waves of the SIMD running the same loop.
 //
-// The number of waves per SIMD is pinned by LDS: every workgroup asks for 160 KB / W of it, so exactly W fit a CU, and the grid is
-// 256 CUs x W workgroups = everything resident at once, one wave of each workgroup per SIMD (with a small LDS footprint the dispatcher
-// packed some CUs fuller than others and the per-SIMD figures of the first version came out below the hardware's 2 cycles per v_fma_f32).
+// The number of waves per SIMD is the workgroup size: ONE workgroup of 256 W threads per CU (100 KB of LDS each, grid = 256 CUs, one
+// round), its 4 W waves dealt over the four SIMDs.  (Earlier versions launched W 256-thread workgroups per CU and let the dispatcher
+// place them: the launch then took twice a wave's loop time -- not every workgroup was resident at once -- and the per-SIMD figures came
+// out too low; `launch_over_loop` checks that here.)
 // s_memtime ticks are shader cycles: the ticks_per_us column (s_memtime against the constant 100 MHz s_memrealtime) reads 2,300-2,400.
 //
 //   hipcc --offload-arch=gfx950 -O3 -o valu_issue_microbench valu_issue_microbench.hip && ./valu_issue_microbench > valu_issue_microbench.json
@@ -122,10 +123,10 @@
                  ::"v"(x), "v"(y), "v"(z) : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v42", "v43", "v44", "v45", "v46", "v47", "s20", "s22", "s23")
 
 #define KERNEL(NAME, BLOCK)                                                                             \
-    __global__ __launch_bounds__(256) void k_##NAME(uint64_t* out, int n, int seed)                     \
+    __global__ __launch_bounds__(1024) void k_##NAME(uint64_t* out, int n, int seed)                     \
     {                                                                                                   \
         extern __shared__ uint32_t lds_dyn[];                                                           \
-        __shared__ uint32_t lds[256];                                                                   \
+        __shared__ uint32_t lds[1024];                                                                  \
         if (seed == -2) lds_dyn[threadIdx.x] = 1;                                                       \
         lds[threadIdx.x] = threadIdx.x * seed;                                                          \
         __syncthreads();                                                                                \
@@ -136,11 +137,11 @@
         for (int i = 0; i < n; ++i) { BLOCK; }                                                          \
         const uint64_t t1 = __builtin_readcyclecounter();                                               \
         const uint64_t r1 = __builtin_amdgcn_s_memrealtime();                                           \
-        if (threadIdx.x == 0 && blockIdx.x == 0) out[(size_t)gridDim.x * 4] = r1 - r0;                  \
+        if (threadIdx.x == 0 && blockIdx.x == 0) out[(size_t)gridDim.x * 16] = r1 - r0;                 \
         uint32_t sink;                                                                                  \
         asm volatile("v_add_u32 %0, v8, v9" : "=v"(sink));                                              \
         if (sink == 0x12345u && seed == -1) lds[0] = sink;                                              \
-        if ((threadIdx.x & 63) == 0) out[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;        \
+        if ((threadIdx.x & 63) == 0) out[(size_t)blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;       \
     }
 
 KERNEL(fma_f32, BLK32_IND(OP_FMA_F32))
@@ -230,39 +231,38 @@ int main()
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount, n = 2000;
-    const int waves[] = {1, 2, 4, 5};       // (W + 1) x (160 KB / W - 256 B) > 160 KB for every W here
+    const int waves[] = {1, 2, 3, 4};       // waves per SIMD = workgroup size / 256: ONE workgroup per CU (100 KB of LDS each), grid = CUs: one round
     uint64_t* d_out;
     hipEvent_t ev0, ev1;
     CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
-    std::vector<uint64_t> h((size_t)cus * 8 * 4 + 1);
+    std::vector<uint64_t> h((size_t)cus * 16 + 1);
     CK(hipMalloc(&d_out, h.size() * sizeof(uint64_t)));
-    printf("{\"device\": \"%s\", \"cus\": %d, \"instructions_per_wave\": %d, \"unit\": \"cycles (s_memtime) per wave-instruction and SIMD = loop cycles / (instructions x waves per SIMD); median over waves\", \"rows\": [\n", prop.gcnArchName, cus, n * 32);
+    printf("{\"device\": \"%s\", \"cus\": %d, \"instructions_per_wave\": %d, \"unit\": \"s_memtime ticks per wave-instruction and SIMD = loop ticks / (instructions x waves per SIMD); median over waves; w<k>_ns: the same from the launch's duration (HIP events)\", \"rows\": [\n", prop.gcnArchName, cus, n * 32);
     bool first = true;
     for (const Entry& e : entries) {
         printf("%s {\"op\": \"%s\"", first ? "" : ",\n", e.name);
         first = false;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
         for (int W : waves) {
-            const int blocks = cus * W;                       // 256-thread workgroups: one wave per SIMD each, exactly W per CU (LDS)
-            const size_t dyn = (size_t)(160 * 1024) / W - 1024 - 256;      // + 1 KB static: W x (dyn + static) <= 160 KB < (W + 1) x
-            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-            hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), dyn, 0, d_out, 50, 1);      // warm the clock / instruction cache
+            const int blocks = cus;
+            const size_t dyn = 100 * 1024;                    // more than half a CU's LDS: one workgroup per CU, 4 W waves = W per SIMD
+            hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256 * W), dyn, 0, d_out, 50, 1);      // warm the clock / instruction cache
             CK(hipEventRecord(ev0, 0));
-            hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), dyn, 0, d_out, n, 1);
+            hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256 * W), dyn, 0, d_out, n, 1);
             CK(hipEventRecord(ev1, 0));
             CK(hipDeviceSynchronize());
             float ms = 0;
             CK(hipEventElapsedTime(&ms, ev0, ev1));
-            CK(hipMemcpy(h.data(), d_out, ((size_t)blocks * 4 + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
-            const double loop_us = (double)h[(size_t)blocks * 4] / 100.;          // s_memrealtime: constant 100 MHz
+            CK(hipMemcpy(h.data(), d_out, ((size_t)blocks * 16 + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            const double loop_us = (double)h[(size_t)blocks * 16] / 100.;          // s_memrealtime: constant 100 MHz
             const double wave0_ticks = (double)h[0];
-            std::vector<uint64_t> v(h.begin(), h.begin() + (size_t)blocks * 4);
+            std::vector<uint64_t> v;
+            for (int b = 0; b < blocks; ++b) for (int w = 0; w < 4 * W; ++w) v.push_back(h[(size_t)b * 16 + w]);
             std::sort(v.begin(), v.end());
             const double med = (double)v[v.size() / 2] / ((double)n * 32 * W);
             printf(", \"w%d\": %.2f", W, med);
-            // the same figure from the wall clock: launch duration (all SIMDs run the same loop) / instructions per SIMD, in ns
             printf(", \"w%d_ns\": %.3f", W, (double)ms * 1e6 / ((double)n * 32 * W));
-            // in-kernel: wave 0's loop on both clocks (s_memtime ticks per microsecond of the constant 100 MHz s_memrealtime)
-            if (W == 5) printf(", \"ticks_per_us\": %.1f, \"w5_loop_ns\": %.3f", wave0_ticks / loop_us, loop_us * 1e3 / ((double)n * 32 * W));
+            if (W == 4) printf(", \"ticks_per_us\": %.1f, \"launch_over_loop\": %.2f", wave0_ticks / loop_us, (double)ms * 1e3 / loop_us);
         }
         printf("}");
         fflush(stdout);

@@ -62,8 +62,8 @@ typedef short av_s2 __attribute__((ext_vector_type(2)));
 // v_pk_maximum3_f16, and the order of non-negative half-precision bit patterns is the order of the integers they spell: the ring
 // differences are biased into 1 .. 511 (subnormal patterns, kept as they are: the kernel runs with fp16 denormals on, the default),
 // compared as halves, and un-biased at the end.  A window minimum of nine = min3(min4, min4, far) is then ONE instruction instead of
-// two, and two windows fold into the running best at once: 56 packed operations per candidate instead of 80 (every one of them costs
-// 2.55 issue cycles, profiles/r05/valu_issue_microbench.json).  Same integers, same scores: tests/test_gpu_ops.py.
+// two, and two windows fold into the running best at once: 56 packed operations per candidate instead of 80 (all of them half-rate
+// instructions, profiles/r05/valu_issue_microbench.json).  Same integers, same scores: tests/test_gpu_ops.py.
 typedef _Float16 av_h2 __attribute__((ext_vector_type(2)));
 typedef unsigned short av_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ av_h2 h2_swap(av_h2 x) { return __builtin_shufflevector(x, x, 1, 0); }

@@ -128,8 +128,9 @@ __device__ __forceinline__ uint32_t pk_mul(uint32_t a, unsigned short k) { av_v2
 // exact sum S over the 16 lanes of a DPP row of an int32 that may overflow when summed (16-bit halves), returned as
 // (float)(S * 2^-20) rounded ONCE -- the value of (float)((double)S * 2^-20), without the fp64 instructions: the two half sums are
 // exact as floats (|hi| < 2^17, lo < 2^18), so is lo * 2^-20, and the fused multiply-add rounds the exact hi * 2^-4 + lo * 2^-20 =
-// S * 2^-20 once.  (fp64 form: 2 x v_cvt_f64_i32, v_ldexp_f64, v_add_f64, v_ldexp_f64, v_cvt_f32_f64 per sum, 4-16 issue cycles
-// each against 2 -- profiles/r05/valu_issue_microbench.json; five sums per Newton iteration and level set-up.)
+// S * 2^-20 once.  (fp64 form: 2 x v_cvt_f64_i32, v_ldexp_f64, v_add_f64, v_ldexp_f64, v_cvt_f32_f64 per sum -- six half-rate
+// instructions against two half-rate conversions, one multiply and one fused multiply-add here; five sums per Newton iteration and
+// level set-up: profiles/r05/valu_issue_microbench.json.)
 __device__ __forceinline__ float row_sum16_scaled(int v)
 {
     // |v| <= 15 * 8160 * 4080 < 2^29: the sum over a quad still fits int32, the sum over 16 lanes does not
@@ -197,7 +198,7 @@ __device__ __forceinline__ void bilin5_seed(uint32_t x0, uint32_t x1, uint32_t x
         "v_sub_u32 %3, %14, %3\n\t"
         "v_sub_u32 %4, %14, %4"
         : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4)
-        // (the two constants in scalar registers: with a 32-bit literal v_and / v_sub cost 1.6 issue cycles instead of 1.0 -- valu_issue_microbench.json)
+        // (the two constants in scalar registers: no 32-bit literal dwords in the instruction stream)
         : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(wtop), "v"(wbot), "v"(rnd), "s"(0xfffffe00u), "s"(0x100u));
 }
 
