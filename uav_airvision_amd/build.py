@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libairvision_hip.so')
 SOURCES = ['ops_api.hip', 'pyramid.hip', 'lk.hip', 'fast.hip', 'frontend.hip', 'msckf.hip', 'png_read.hip']
-HEADERS = ['av_common.h', 'msckf_batch.inc', 'msckf_store.h', 'msckf_dev.inc', 'msckf_dev_host.inc', os.path.join('..', '..', 'include', 'airvision.h')]
+HEADERS = ['av_common.h', 'msckf_batch.inc', 'msckf_mfma.inc', 'msckf_store.h', 'msckf_dev.inc', 'msckf_dev_host.inc', os.path.join('..', '..', 'include', 'airvision.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
          '-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt', '-fno-fast-math', '-fopenmp',
          '-Wall', '-Wno-unused-function']

@@ -357,12 +357,14 @@ __device__ __forceinline__ void lk_patch_rows(LoadRow load_row, uint32_t wtop, u
     if (r >= WIN) { a11 = 0; a12 = 0; a22 = 0; }
 }
 
-template <int WIN, int OCC, bool PROF = false>
+// PTS: points per workgroup (16 = four wavefronts, 4 = one).  The wavefronts of a workgroup share nothing -- every point has its own
+// LDS tile and there is no barrier -- so the workgroup size is purely a placement matter: see lk_track_g16_w1_kernel.
+template <int WIN, int OCC, bool PROF = false, int PTS = 16>
 __device__ __forceinline__ bool lk_track_g16_body(const LKArgs& a)
 {
     static_assert(WIN == 15, "lane map is built for the reference's 15x15 window");
     constexpr int W_BITS = 14;
-    __shared__ uint32_t tile_all[16][TILE_DWORDS];
+    __shared__ uint32_t tile_all[PTS][TILE_DWORDS];
     // phase stamps (PROF only): cycles since the previous stamp are booked on the phase that just ended
     unsigned pt[LKP_N] = {0, 0, 0, 0, 0}, plast = 0;             // 32-bit: a wavefront lives ~10^5 cycles
     unsigned pn_iter = 0, pn_restage = 0, pn_level = 0;
@@ -380,7 +382,7 @@ __device__ __forceinline__ bool lk_track_g16_body(const LKArgs& a)
     int s, bx;
     if (a.gx > 0) { const int L = blockIdx.x, j = L >> 3; s = (L & 7) + 8 * (j / a.gx); bx = j % a.gx; if (s >= a.n_set) return false; }
     else { s = blockIdx.y; bx = blockIdx.x; }
-    const int slot = bx * 16 + g;
+    const int slot = bx * PTS + g;
     const int sI = a.mapI ? a.mapI[s] : s, sJ = a.mapJ ? a.mapJ[s] : s;      // storage entries of the two images (scalar loads)
     if (sI < 0 || sJ < 0) return false;
     // Without an index list the point of a slot is known before the set's count is: its loads are issued ahead of the count's (one
@@ -624,6 +626,10 @@ __device__ __forceinline__ bool lk_track_g16_body(const LKArgs& a)
 // 96 VGPRs: 5 waves per SIMD without spills (the kernel is VALU-issue bound: 4 -> 5 waves bought 1 %, a 6-wave build with
 // 11 spilled values lost 5 %).
 template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_kernel(LKArgs a) { lk_track_g16_body<WIN, 5>(a); }
+// One wavefront (four points) per workgroup.  A 256-thread workgroup needs a free slot on all four SIMDs of a CU at once: beside the
+// filter's single-wavefront tasks, each of which takes ONE slot on ONE SIMD, a CU with three free slots starts nothing -- every
+// resident filter wavefront can keep a whole LK workgroup out.  Single wavefronts are placed slot by slot.
+template <int WIN> __global__ __launch_bounds__(64, 5) void lk_track_g16_w1_kernel(LKArgs a) { lk_track_g16_body<WIN, 5, false, 4>(a); }
 // (Forward and backward pass of a stereo match as ONE launch -- the 16 lanes that tracked a point forward track it back, three launches
 //  fewer per front-end step -- was built and measured in round 5: front-end alone 207.9 / 206.2 k against 206.1 / 206.8 k frames/s, one
 //  stream 0.649 against 0.645 ms per frame: nothing, removed.  profiles/r05/README.md)
@@ -848,10 +854,10 @@ static bool lk_prof_on()
 }
 
 // grid of the 16-lane kernels: XCD-aware 1-D launch (lk_track_g16_body) unless AV_LK_XCD=0
-static dim3 lk_g16_grid(LKArgs& a, int n_set, int launch_pts)
+static dim3 lk_g16_grid(LKArgs& a, int n_set, int launch_pts, int pts_per_wg)
 {
     static const bool xcd_map = [] { const char* e = getenv("AV_LK_XCD"); return !(e && atoi(e) == 0); }();      // A/B switch
-    const int gx = (launch_pts + 15) / 16;
+    const int gx = (launch_pts + pts_per_wg - 1) / pts_per_wg;
     a.n_set = n_set; a.gx = xcd_map ? gx : 0;
     return xcd_map ? dim3((unsigned)gx * 8u * (unsigned)((n_set + 7) / 8)) : dim3(gx, n_set);
 }
@@ -872,10 +878,12 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
         AV_LAUNCH_CHECK();
         return AV_OK;
     }
-    const dim3 grid = lk_g16_grid(a, n_set, launch_pts);
     const bool prof = lk_prof_on();
+    static const bool w1 = [] { const char* e = getenv("AV_LK_WG"); return e && atoi(e) == 64; }();      // A/B switch: one wavefront per workgroup
+    const dim3 grid = lk_g16_grid(a, n_set, launch_pts, (w1 && !prof) ? 4 : 16);
     a.prof = g_lk_prof;
     if (prof) hipLaunchKernelGGL(lk_track_g16_prof_kernel<15>, grid, dim3(256), 0, st, a);
+    else if (w1) hipLaunchKernelGGL(lk_track_g16_w1_kernel<15>, grid, dim3(64), 0, st, a);
     else hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;

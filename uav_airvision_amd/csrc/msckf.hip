@@ -316,13 +316,13 @@ __device__ __forceinline__ void triangulate_one(const TriArgs& a, int f, int lan
 __global__ __launch_bounds__(256) void triangulate_kernel(TriArgs a)
 {
     AV_FILTER_PRIO();
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wpb = (int)blockDim.x >> 6;      // wavefronts per workgroup: 4, or 1 (device-resident path)
     if (a.list) {                                           // wave-uniform loop: a wavefront per listed feature
         const int n = *a.n_list_dev;
-        for (int t = blockIdx.x * 4 + (threadIdx.x >> 6); t < n; t += gridDim.x * 4) triangulate_one(a, a.list[t], lane);
+        for (int t = blockIdx.x * wpb + (threadIdx.x >> 6); t < n; t += gridDim.x * wpb) triangulate_one(a, a.list[t], lane);
         return;
     }
-    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int f = blockIdx.x * wpb + (threadIdx.x >> 6);
     if (f >= a.n_feat) return;
     triangulate_one(a, f, lane);
 }
@@ -2096,6 +2096,28 @@ __global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict
         const int r = e / k, c = e - r * k;
         a.Sbuf[(size_t)r * a.ld + c] = ok ? (c <= r ? at(r, c) : at(c, r)) : (r == c ? 1e150 : 0.0);
     }
+    // Transposed inverses of L's 16 x 16 diagonal blocks for the blocked substitution (upd_fsolve_mfma_kernel): block I at Pn + 256 I
+    // (Pn is free on the batched path: upd_p works in place), LinvT[kk][i] = Linv_II[i][kk].  A thread per column of an inverse:
+    // forward substitution of the unit vector against the block in LDS.  Rows at or beyond k: identity; after a bad pivot 1e-150 I.
+    {
+        const int I = tid >> 4, j = tid & 15, i0 = 16 * I;
+        if (i0 < k) {
+            double x[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int gi = i0 + i;
+                double v = i == j ? 1.0 : 0.0;
+                if (gi < k && ok) {
+#pragma unroll
+                    for (int t = 0; t < i; ++t) v = __builtin_fma(-at(gi, i0 + t), x[t], v);      // (x[t] = 0 for t < j)
+                    v = i < j ? 0.0 : v / at(gi, gi);
+                } else if (!ok) v *= 1e-150;
+                x[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a.Pn[I * 256 + j * 16 + i] = x[i];
+        }
+    }
     stamp(11);
     if (a.prof && tid == 0) a.prof[12] = (unsigned long long)k;
 }
@@ -2995,4 +3017,44 @@ AV_EXPORT int av_msckf_update(av_msckf* c, const int32_t* blk_row_dev, const int
     return AV_OK;
 }
 
+#include "msckf_mfma.inc"
+
+// The back end of one round of batched updates: T^T, S, its factor, the substitution, the covariance update -- for all S streams of
+// `arr` (streams without an update of this kind exit on their first instruction).  kmax / nmax: the longest pass / largest state the
+// grids have to cover.  AV_MSCKF_MFMA=0 (A/B) takes the 64 x 64 LDS tile kernels of rounds 3-4 instead of the matrix-instruction ones.
+static inline bool upd_mfma_on() { static const bool on = [] { const char* e = getenv("AV_MSCKF_MFMA"); return !(e && atoi(e) == 0); }(); return on; }
+static inline void launch_upd_back(const UpdArgs* arr, int S, int kmax, int nmax, size_t lds_s, hipStream_t stm, int skipk = 0)
+{
+    if (upd_mfma_on()) {
+        const int bk = (kmax + MBW - 1) / MBW, bn = (nmax + MBW - 1) / MBW;
+        if (!(skipk & 8)) hipLaunchKernelGGL(upd_tt_mfma_kernel, dim3(mfma_grid(bn * bk, S)), dim3(64), 0, stm, arr, S, bn, bk);
+        if (!(skipk & 8)) hipLaunchKernelGGL(upd_s_mfma_kernel, dim3(mfma_grid(bk * (bk + 1) / 2, S)), dim3(64), 0, stm, arr, S, bk);
+        static const bool chol_lds = [] { const char* e = getenv("AV_MSCKF_CHOL"); return e && !strcmp(e, "lds"); }();      // A/B: the 256-thread LDS factor kernel
+        if (!(skipk & 16)) {
+            if (chol_lds) hipLaunchKernelGGL(upd_chol_kernel, dim3(S), dim3(256), lds_s, stm, arr, 0, 1 << 30);
+            else hipLaunchKernelGGL(upd_chol_mfma_kernel, dim3(mfma_grid(1, S)), dim3(64), 0, stm, arr, S);
+        }
+        const int parts = nmax / 16 + 1;
+        if (!(skipk & 32)) hipLaunchKernelGGL(upd_fsolve_mfma_kernel, dim3(mfma_grid(parts, S)), dim3(64), 0, stm, arr, S, parts);
+        if (!(skipk & 64)) hipLaunchKernelGGL(upd_p_mfma_kernel, dim3(mfma_grid(bn * (bn + 1) / 2, S)), dim3(64), 0, stm, arr, S, bn);
+        return;
+    }
+    const int tk = (kmax + GT - 1) / GT, tn = (nmax + GT - 1) / GT;
+    if (!(skipk & 8)) hipLaunchKernelGGL(upd_tt_kernel, dim3(tn * tk, S), dim3(256), 0, stm, arr, tk);
+    if (!(skipk & 8)) hipLaunchKernelGGL(upd_s_kernel, dim3(tk * (tk + 1) / 2, S), dim3(256), 0, stm, arr);
+    if (!(skipk & 16)) hipLaunchKernelGGL(upd_chol_kernel, dim3(S), dim3(256), lds_s, stm, arr, 0, 1 << 30);
+    if (!(skipk & 32)) hipLaunchKernelGGL(upd_fsolve16_kernel, dim3((nmax + 64) / 64, S), dim3(64), 0, stm, arr);
+    if (!(skipk & 64)) hipLaunchKernelGGL(upd_p_kernel, dim3(tn * (tn + 1) / 2, S), dim3(256), 0, stm, arr);
+}
+// Partial Gram slabs of the streams on `list` (n_list_dev: device-written count, the tasks stride over the list; NULL: n_list entries)
+static inline void launch_upd_gram(const UpdArgs* arr, const int* list, const int* n_list_dev, unsigned n_list, unsigned nsl, int k1max, hipStream_t stm)
+{
+    if (upd_mfma_on()) {
+        const int bk = (k1max + MBW - 1) / MBW, slots = 8 * (int)((n_list + 7) / 8);
+        hipLaunchKernelGGL(upd_gram_mfma_kernel, dim3((unsigned)(bk * (bk + 1) / 2) * nsl * (unsigned)slots), dim3(64), 0, stm, arr, list, n_list_dev, (int)n_list, slots, (int)nsl, bk);
+        return;
+    }
+    const int gt = (k1max + GT - 1) / GT;
+    hipLaunchKernelGGL(upd_gram_kernel, dim3(gt * (gt + 1) / 2, nsl, n_list), dim3(256), 0, stm, arr, list, n_list_dev);
+}
 #include "msckf_batch.inc"
