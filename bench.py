@@ -571,6 +571,10 @@ def main():
             return 4
         fe_stream = torch.cuda.ExternalStream(hs.value, device=dev)
         torch.cuda.set_stream(fe_stream)
+    elif os.environ.get('AV_FE_PRIO'):           # A/B: the front-end's launches on a stream of the highest (2) / lowest (0) HIP priority
+        lo_hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else (0, -1)
+        fe_stream = torch.cuda.Stream(device=dev, priority=(min(lo_hi) if os.environ['AV_FE_PRIO'] == '2' else max(lo_hi)))
+        torch.cuda.set_stream(fe_stream)
     eng = FrontendEngine(cfg, n_streams=S, device=local_rank, inputs_persist=True)      # every frame of the run is resident in HBM
     flt = None
     if with_msckf:
@@ -763,8 +767,8 @@ def main():
             fl = dw['gate_flops'] + dw['update_flops']
             tf = fl / (dw['chain_ms'] * 1e-3) / 1e12 if dw['chain_ms'] > 0 else 0.0
             out['roofline_msckf'] = {
-                'bound': 'fp64 vector FMA (= fp64 MFMA peak on MI355X); the stage itself is latency / LDS bound (SURVEY 8d)',
-                'kernels': 'triangulate, feature_kernel<256> / feature_kernel8, upd_stack, upd_rowmap/gram/gram_chol, upd_gather/tt/s/chol/fsolve/p, upd_info (device-resident filter: the spans also hold dk_mid)',
+                'bound': 'fp64 FMA peak (vector = matrix instruction on MI355X: profiles/r05/mfma_f64_probe.json); the stage itself is bound by dependent chains and placement beside the front-end (SURVEY 8d)',
+                'kernels': 'triangulate, feature_kernel<256> / feature_kernel8, upd_stack, upd_rowmap, upd_gram_mfma / upd_gram_chol_mfma, upd_gather, upd_tt_mfma / upd_s_mfma / upd_chol_mfma / upd_fsolve_mfma / upd_p_mfma (single-wavefront tasks on v_mfma_f64_16x16x4), upd_info (device-resident filter: the spans also hold dk_mid)',
                 'achieved': tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / FP64_PEAK_TFLOPS,
                 'algorithmic_flops_per_step': fl / K, 'gate_flops_per_step': dw['gate_flops'] / K, 'update_flops_per_step': dw['update_flops'] / K,
                 'reference_qr_flops_per_step_not_counted': dw['reference_qr_flops'] / K,
@@ -772,7 +776,7 @@ def main():
                 'updates_per_stream_step': dw['updates'] / K / S,
                 'chain_ms_per_step': dw['chain_ms'] / K,
                 # the same stage by the flops the kernels EXECUTE on their block-sparse shapes (av_msckf_batch_work_executed: analytic
-                # per gated feature / per update, tile padding not counted) -- the dense formulas above price a 21-observation gate
+                # per gated feature / per update; the matrix-instruction products WITH their 16 x 16 x 4 padding) -- the dense formulas above price a 21-observation gate
                 # at 5.5 MFLOP where feature_kernel runs ~0.6
                 'executed': {'flops_per_step': (dw['gate_flops_executed'] + dw['update_flops_executed']) / K,
                              'gate_flops_per_step': dw['gate_flops_executed'] / K, 'update_flops_per_step': dw['update_flops_executed'] / K,

@@ -358,7 +358,7 @@ __device__ __forceinline__ void lk_patch_rows(LoadRow load_row, uint32_t wtop, u
 }
 
 // PTS: points per workgroup (16 = four wavefronts, 4 = one).  The wavefronts of a workgroup share nothing -- every point has its own
-// LDS tile and there is no barrier -- so the workgroup size is purely a placement matter: see lk_track_g16_w1_kernel.
+// LDS tile and there is no barrier -- so the workgroup size is purely a placement matter: see lk_track_g16_kernel.
 template <int WIN, int OCC, bool PROF = false, int PTS = 16>
 __device__ __forceinline__ bool lk_track_g16_body(const LKArgs& a)
 {
@@ -625,11 +625,15 @@ __device__ __forceinline__ bool lk_track_g16_body(const LKArgs& a)
 //  leaves; the kernel is bound by VALU issue.)
 // 96 VGPRs: 5 waves per SIMD without spills (the kernel is VALU-issue bound: 4 -> 5 waves bought 1 %, a 6-wave build with
 // 11 spilled values lost 5 %).
-template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_kernel(LKArgs a) { lk_track_g16_body<WIN, 5>(a); }
-// One wavefront (four points) per workgroup.  A 256-thread workgroup needs a free slot on all four SIMDs of a CU at once: beside the
+// One wavefront (four points) per workgroup: the wavefronts of this kernel share nothing, so the workgroup size is a placement matter
+// only -- and it matters twice.  (1) A 256-thread workgroup holds its four slots until its SLOWEST wavefront is done (the points of a
+// launch take 3 .. 30 Newton iterations); single wavefronts hand their slot back one by one: front-end alone 0.917 -> 0.862 ms per
+// launch (211.1 -> 220.5 k frames/s).  (2) A 256-thread workgroup needs a free slot on all four SIMDs of a CU at once: beside the
 // filter's single-wavefront tasks, each of which takes ONE slot on ONE SIMD, a CU with three free slots starts nothing -- every
-// resident filter wavefront can keep a whole LK workgroup out.  Single wavefronts are placed slot by slot.
-template <int WIN> __global__ __launch_bounds__(64, 5) void lk_track_g16_w1_kernel(LKArgs a) { lk_track_g16_body<WIN, 5, false, 4>(a); }
+// resident filter wavefront can keep a whole LK workgroup out: complete path 161.6 -> 168.9 k.  (profiles/r05/README.md)
+template <int WIN> __global__ __launch_bounds__(64, 5) void lk_track_g16_kernel(LKArgs a) { lk_track_g16_body<WIN, 5, false, 4>(a); }
+// AV_LK_WG=256 (A/B): four wavefronts (16 points) per workgroup, rounds 2-4's launch shape
+template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_w4_kernel(LKArgs a) { lk_track_g16_body<WIN, 5>(a); }
 // (Forward and backward pass of a stereo match as ONE launch -- the 16 lanes that tracked a point forward track it back, three launches
 //  fewer per front-end step -- was built and measured in round 5: front-end alone 207.9 / 206.2 k against 206.1 / 206.8 k frames/s, one
 //  stream 0.649 against 0.645 ms per frame: nothing, removed.  profiles/r05/README.md)
@@ -879,12 +883,12 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
         return AV_OK;
     }
     const bool prof = lk_prof_on();
-    static const bool w1 = [] { const char* e = getenv("AV_LK_WG"); return e && atoi(e) == 64; }();      // A/B switch: one wavefront per workgroup
+    static const bool w1 = [] { const char* e = getenv("AV_LK_WG"); return !(e && atoi(e) == 256); }();      // one wavefront per workgroup; AV_LK_WG=256 (A/B): four
     const dim3 grid = lk_g16_grid(a, n_set, launch_pts, (w1 && !prof) ? 4 : 16);
     a.prof = g_lk_prof;
     if (prof) hipLaunchKernelGGL(lk_track_g16_prof_kernel<15>, grid, dim3(256), 0, st, a);
-    else if (w1) hipLaunchKernelGGL(lk_track_g16_w1_kernel<15>, grid, dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(256), 0, st, a);
+    else if (w1) hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(lk_track_g16_w4_kernel<15>, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;
 }

@@ -1827,22 +1827,15 @@ __device__ __forceinline__ void update_back(const UpdArgs& a)
     stamp(6);
 }
 // ================================================================================================
-// Back end of the stacked update for MANY streams (av_msckf_batch_*): the three GEMM-shaped phases as wide-grid tile
-// kernels over all streams (64 x 64 output tile per 256-thread workgroup, 4 x 4 per thread, operands staged through LDS in
-// panels of 16), and the two dependent chains -- Cholesky of S and the forward substitution -- in a 256-thread kernel per
-// stream that holds only the packed factor in LDS.  The single-workgroup update_back above does the same arithmetic inside
-// one 1024-thread workgroup at 128 VGPRs: it owns a whole CU for ~0.4 ms per stream while using a few percent of it, and
-// nothing else can be resident beside it; these kernels are <= 64 VGPRs each, so the front-end's kernels share the CUs.
-//   T^T = P[:, cols] H_thin^T   (n x k)      upd_tt_kernel
-//   S   = H_thin P_cc H_thin^T + s^2 I        upd_s_kernel      (rows cols[q] of T^T are exactly P_cc H_thin^T)
-//   L L^T = S                                  upd_chol_kernel   (blocked, LDS)
-//   Y = L^-1 [T | r]                           upd_fsolve16_kernel (a lane per right-hand side, L through the scalar cache)
-//   P  <- sym(P - Y^T Y) in place, dx = Y^T y_r   upd_p_kernel
-// fp64 MFMA is not used: on MI355X the fp64 matrix peak equals the fp64 vector peak (78.6 TFLOP/s, CDNA4 halved the
-// MI300's fp64 matrix rate), so v_mfma_f64_16x16x4 buys no throughput over v_fma_f64 and costs the fragment shuffles.
+// Back end of the stacked update for MANY streams (av_msckf_batch_*): msckf_mfma.inc (included below, after the kernels whose helpers it
+// shares) -- T^T = P[:, cols] H_thin^T, S = H_thin P_cc H_thin^T + s^2 I, L L^T = S, Y = L^-1 [T | r], P <- sym(P - Y^T Y) as
+// single-wavefront tasks on the fp64 matrix instruction.  The single-workgroup update_back above does the same arithmetic inside one
+// 1024-thread workgroup at 128 VGPRs (the single-filter path): it owns a whole CU for ~0.4 ms per stream while using a few percent of it.
+// (Rounds 3-5 ran these products as 64 x 64 LDS tile kernels -- 256-thread workgroups, 4 x 4 fp64 register tiles, panels of 16 -- around
+//  a 256-thread factor kernel with the packed triangle in 74 KB of LDS and a lane-per-right-hand-side substitution: git 26affda.  A 48-wide
+//  wave-tile variant of them, one 576-thread workgroup per stream, was slower still: 148.6 k against 155.8 k frames/s.  profiles/r05/README.md
+//  has the numbers that retired them: 315 / 247 / 490 / 426 / 375 us per 2,048-stream launch alone and 2-5x that beside the front-end.)
 // ================================================================================================
-constexpr int GT = 64, GQ = 16, GP = GT + 4;      // tile edge, panel depth, LDS pitch in doubles (16-B aligned rows)
-
 // Pointers that arrive inside a struct read from memory (UpdArgs) are generic to the compiler: it emits FLAT loads, which count on
 // lgkmcnt as well as vmcnt -- an LDS-only barrier would wait for them.  These casts say "global memory" (global_load: vmcnt only).
 typedef const double __attribute__((address_space(1)))* gcd_ptr;
@@ -1851,388 +1844,9 @@ typedef const int __attribute__((address_space(1)))* gci_ptr;
 #define AV_GI(p) ((gci_ptr)(p))
 
 // Workgroup barrier for LDS hand-overs only: the LDS writes of this wavefront are done (lgkmcnt(0)) and every wavefront has arrived.
-// __syncthreads() also drains vmcnt -- every global load or store in flight has to come back first -- which is what makes a
-// register-prefetched panel loop pointless: the loads issued for the NEXT panel would be waited for at THIS panel's barrier.
+// __syncthreads() also drains vmcnt -- every global load or store in flight has to come back first.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// 64 x 64 output tile, panels of GQ: the next panel's operands are fetched into registers while the current one is multiplied out of
-// LDS (two LDS buffers, one barrier per panel).  The un-pipelined form (load, barrier, multiply, barrier) paid one full global-memory
-// latency per panel -- PMC, round 4: the tile kernels waited 77-79 % of their wave cycles and issued VALU in 9 %.
-// The caller separates consecutive calls by a barrier.
-// rlim / clim: outputs at or beyond them are never used -- a thread whose whole 4 x 4 sub-tile lies outside multiplies nothing (it still
-// stages its share of the panels).  Rows map to wavefronts (ty = tid / 16: four rows of sub-tiles per wavefront), so the 13 valid rows of
-// the third row of tiles of a 141-row product cost one wavefront's multiply-adds instead of four.
-template <typename FA, typename FB>
-__device__ __forceinline__ void gemm_tile64(int Q, int r0, int c0, FA loadA, FB loadB, double (&acc)[4][4], int rlim = 1 << 30, int clim = 1 << 30)
-{
-    __shared__ __attribute__((aligned(16))) double pa[2][GQ * GP], pb[2][GQ * GP];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const bool active = r0 + 4 * ty < rlim && c0 + 4 * tx < clim;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-    double ra[4], rb[4];
-    auto fetch = [&](int q0) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = tid + 256 * u, q = idx >> 6, e = idx & 63;
-            const bool in = q0 + q < Q;
-            ra[u] = in ? loadA(q0 + q, r0 + e) : 0.0;
-            rb[u] = in ? loadB(q0 + q, c0 + e) : 0.0;
-        }
-    };
-    fetch(0);
-    int buf = 0;
-    for (int q0 = 0; q0 < Q; q0 += GQ) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = tid + 256 * u, q = idx >> 6, e = idx & 63;
-            pa[buf][q * GP + e] = ra[u];
-            pb[buf][q * GP + e] = rb[u];
-        }
-        if (q0 + GQ < Q) fetch(q0 + GQ);                   // in flight during the products below
-        lds_barrier();
-        if (active) {
-#pragma unroll
-            for (int q = 0; q < GQ; ++q) {
-                const av_d4 av = *reinterpret_cast<const av_d4*>(&pa[buf][q * GP + 4 * ty]);
-                const av_d4 bv = *reinterpret_cast<const av_d4*>(&pb[buf][q * GP + 4 * tx]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(av[i], bv[j], acc[i][j]);
-            }
-        }
-        buf ^= 1;
-    }
-}
-
-// T^T[c][r] = sum_q P[cols[q]][c] * Wt[q][r]   (c < n, r < k), stored [n][ld] in a.T
-__global__ __launch_bounds__(256) void upd_tt_kernel(const UpdArgs* __restrict__ arr, int tiles_k)
-{
-    AV_FILTER_PRIO();
-    const UpdArgsG a = upd_load(arr, blockIdx.y);
-    if (a.m <= 0 || a.mode != 0) return;
-    const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc)), n = a.n;
-    const int r0 = (blockIdx.x / tiles_k) * GT, c0 = (blockIdx.x % tiles_k) * GT;      // rows: state index, columns: stacked row
-    if (r0 >= n || c0 >= k) return;
-    const size_t ldt = a.ldt;
-    double acc[4][4];
-    gemm_tile64(a.nc, r0, c0,
-                [&](int q, int c) { return c < n ? AV_GD(a.P)[(size_t)AV_GI(a.cols)[q] * a.ld + c] : 0.0; },
-                [&](int q, int r) { return r < k ? AV_GD(a.W)[(size_t)q * ldt + r] : 0.0; }, acc, n, k);
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = r0 + 4 * ty + i;
-        // columns at or beyond k (rounded up to the 4-wide store) belong to nobody: a 64-wide tile may reach past the row pitch
-        if (c < n && c0 + 4 * tx < k) { av_d4 o = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]}; *(av_gptr<av_d4>)(a.T + (size_t)c * a.ld + c0 + 4 * tx) = o; }
-    }
-}
-
-// S[r][c] = sum_q T^T[cols[q]][r] * Wt[q][c] + s^2 [r == c]   (r, c < k; tiles on and below the diagonal)
-__global__ __launch_bounds__(256) void upd_s_kernel(const UpdArgs* __restrict__ arr)
-{
-    AV_FILTER_PRIO();
-    const UpdArgsG a = upd_load(arr, blockIdx.y);
-    if (a.m <= 0 || a.mode != 0) return;
-    const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
-    int tr = (int)((sqrtf(8.f * blockIdx.x + 1.f) - 1.f) * 0.5f);              // triangular tile index -> (tr, tc), tc <= tr
-    while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
-    while (tr * (tr + 1) / 2 > (int)blockIdx.x) --tr;
-    const int tc = blockIdx.x - tr * (tr + 1) / 2;
-    const int r0 = tr * GT, c0 = tc * GT;
-    if (r0 >= k) return;
-    const size_t ldt = a.ldt;
-    double acc[4][4];
-    gemm_tile64(a.nc, r0, c0,
-                [&](int q, int r) { return r < k ? AV_GD(a.T)[(size_t)AV_GI(a.cols)[q] * a.ld + r] : 0.0; },
-                [&](int q, int c) { return c < k ? AV_GD(a.W)[(size_t)q * ldt + c] : 0.0; }, acc, k, k);
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = r0 + 4 * ty + i;
-        if (r < k && c0 + 4 * tx < k) {
-            av_d4 o = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (c0 + 4 * tx + j == r) o[j] += a.obs_noise;
-            *(av_gptr<av_d4>)(a.Sbuf + (size_t)r * a.ld + c0 + 4 * tx) = o;       // k <= 144 < ld: the 4-wide store stays inside the row
-        }
-    }
-}
-
-// Cholesky S = L L^T: packed lower triangle in LDS, blocked right-looking with panels of 8 columns -- the 8 x 8 diagonal
-// block is factored by one thread in registers, the panel below it one row per thread, the trailing block by a 16 x 16 thread
-// grid: three barriers per EIGHT columns (the unblocked form pays one per column, and the barrier is most of a step at
-// these sizes).  L goes back to Sbuf (row-major) for the substitution kernel, which reads it through the scalar cache.
-constexpr int CNB = 8;
-// in-place blocked Cholesky of the packed lower triangle Lp (k x k) by a 256-thread workgroup; ends on a barrier.
-// Returns false (to every thread) if a pivot was not positive and finite -- the matrix was not positive definite to working
-// precision, or held a NaN / Inf; the factor is then meaningless (the bad pivot is replaced by 1 so that nothing traps) and
-// the caller must not use it.
-__device__ __forceinline__ bool chol_packed_lds(double* Lp, int k, int tid)
-{
-    __shared__ int chol_bad;
-    __shared__ double dinv[CNB];                            // reciprocals of the panel's diagonal (the panel rows multiply, they do not divide)
-    if (tid == 0) chol_bad = 0;
-    auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
-    for (int j0 = 0; j0 < k; j0 += CNB) {
-        const int nb = min(CNB, k - j0), jb = j0 + nb;
-        if (tid == 0) {                                    // diagonal block: Cholesky of nb x nb in registers
-            double A[CNB][CNB];
-#pragma unroll
-            for (int i = 0; i < CNB; ++i)
-#pragma unroll
-                for (int j = 0; j <= i; ++j) A[i][j] = (i < nb) ? at(j0 + i, j0 + j) : (i == j ? 1.0 : 0.0);
-#pragma unroll
-            for (int j = 0; j < CNB; ++j) {
-                double d = A[j][j];
-#pragma unroll
-                for (int t = 0; t < j; ++t) d -= A[j][t] * A[j][t];
-                if (!(d > 0.0) || !(d < 1.79e308)) { if (j < nb) chol_bad = 1; d = 1.0; }
-                const double inv = av_rsqrt_f64(d);
-                d = d * inv;
-                A[j][j] = d;
-                dinv[j] = inv;
-#pragma unroll
-                for (int i = j + 1; i < CNB; ++i) {
-                    double v = A[i][j];
-#pragma unroll
-                    for (int t = 0; t < j; ++t) v -= A[i][t] * A[j][t];
-                    A[i][j] = v * inv;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < CNB; ++i)
-#pragma unroll
-                for (int j = 0; j <= i; ++j) if (i < nb) at(j0 + i, j0 + j) = A[i][j];
-        }
-        __syncthreads();
-        if (jb >= k) break;
-        for (int r = jb + tid; r < k; r += 256) {          // panel: row r of L21 = A21 L11^-T
-            double x[CNB];
-#pragma unroll
-            for (int t = 0; t < CNB; ++t) x[t] = t < nb ? at(r, j0 + t) : 0.0;
-#pragma unroll
-            for (int t = 0; t < CNB; ++t) if (t < nb) {
-                double v = x[t];
-#pragma unroll
-                for (int u = 0; u < t; ++u) v -= x[u] * at(j0 + t, j0 + u);
-                x[t] = v * dinv[t];
-            }
-#pragma unroll
-            for (int t = 0; t < CNB; ++t) if (t < nb) at(r, j0 + t) = x[t];
-        }
-        __syncthreads();
-        // trailing block: A22 -= L21 L21^T (lower triangle).  CTR rows (r, r + 16, ...) per thread and pass: the eight panel entries of a
-        // column are read from LDS once for all of them -- the factorisation is bound by LDS traffic (two workgroups on a CU take twice as
-        // long as one): 8 + 2 CTR LDS operations per 8 CTR multiply-adds where one row at a time made 10 per 8 (659 -> 564 us per
-        // 2,048-stream launch at CTR = 2).
-        constexpr int CTR = 2;                               // (CTR = 4: the same 557 us -- the rest of a panel step is what is left)
-        for (int r0 = jb + (tid >> 4); r0 < k; r0 += 16 * CTR) {
-            double lr[CTR][CNB];
-#pragma unroll
-            for (int u = 0; u < CTR; ++u)
-#pragma unroll
-                for (int t = 0; t < CNB; ++t) lr[u][t] = (r0 + 16 * u < k && t < nb) ? at(r0 + 16 * u, j0 + t) : 0.0;
-            const int rlast = min(r0 + 16 * (CTR - 1), k - 1 - ((k - 1 - r0) % 16));       // the last of this thread's rows that exists
-            for (int c = jb + (tid & 15); c <= rlast; c += 16) {
-                double lc[CNB];
-#pragma unroll
-                for (int t = 0; t < CNB; ++t) lc[t] = t < nb ? at(c, j0 + t) : 0.0;
-#pragma unroll
-                for (int u = 0; u < CTR; ++u) {
-                    const int r = r0 + 16 * u;
-                    if (r < k && c <= r) {
-                        double v = at(r, c);
-#pragma unroll
-                        for (int t = 0; t < CNB; ++t) v -= lr[u][t] * lc[t];
-                        at(r, c) = v;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    return chol_bad == 0;
-}
-// k_lo < k <= k_hi: the launch's LDS is sized for k_hi (a launch per length class was tried and lost: msckf_dev_host.inc).
-__global__ __launch_bounds__(256) void upd_chol_kernel(const UpdArgs* __restrict__ arr, int k_lo, int k_hi)
-{
-    AV_FILTER_PRIO();
-    extern __shared__ double Lp[];
-    const UpdArgsG a = upd_load(arr, blockIdx.x);
-    if (a.m <= 0 || a.mode != 0) return;
-    const int tid = threadIdx.x;
-    const int k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
-    if (k <= k_lo || k > k_hi) return;
-    auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
-    auto stamp = [&](int i) { if (a.prof && tid == 0) a.prof[i] = __builtin_amdgcn_s_memrealtime(); };
-    stamp(8);
-    // (four loads in flight per thread: as a plain loop every entry waited for its own round trip -- 20 us of a 90 us workgroup)
-    for (int e0 = tid; e0 < k * k; e0 += 256 * 4) {
-        double v[4]; int idx[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + 256 * u, r = e / k, c = e - r * k;
-            const bool ok = e < k * k && c <= r;
-            idx[u] = ok ? r * (r + 1) / 2 + c : -1;
-            v[u] = ok ? a.Sbuf[(size_t)r * a.ld + c] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (idx[u] >= 0) Lp[idx[u]] = v[u];
-    }
-    __syncthreads();
-    stamp(9);
-    const bool ok = chol_packed_lds(Lp, k, tid);
-    stamp(10);
-    if (!ok && tid == 0 && a.status) *a.status = UPD_BAD_PIVOT;      // S = H P H^T + s^2 I not positive definite: the covariance is corrupt
-    // L is written as a symmetric matrix: the substitution kernel reads eight consecutive rows of one COLUMN of L per step,
-    // which the mirrored upper triangle holds contiguously (one 64-byte scalar load instead of eight).
-    // After a bad pivot L = 1e150 I is written instead: Y = L^-1 [T | r] ~ 0, so delta_x = 0 and P stays as it is (no NaN reaches
-    // the state); the host stops the stream on the flag.
-    for (int e = tid; e < k * k; e += 256) {
-        const int r = e / k, c = e - r * k;
-        a.Sbuf[(size_t)r * a.ld + c] = ok ? (c <= r ? at(r, c) : at(c, r)) : (r == c ? 1e150 : 0.0);
-    }
-    // Transposed inverses of L's 16 x 16 diagonal blocks for the blocked substitution (upd_fsolve_mfma_kernel): block I at Pn + 256 I
-    // (Pn is free on the batched path: upd_p works in place), LinvT[kk][i] = Linv_II[i][kk].  A thread per column of an inverse:
-    // forward substitution of the unit vector against the block in LDS.  Rows at or beyond k: identity; after a bad pivot 1e-150 I.
-    {
-        const int I = tid >> 4, j = tid & 15, i0 = 16 * I;
-        if (i0 < k) {
-            double x[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int gi = i0 + i;
-                double v = i == j ? 1.0 : 0.0;
-                if (gi < k && ok) {
-#pragma unroll
-                    for (int t = 0; t < i; ++t) v = __builtin_fma(-at(gi, i0 + t), x[t], v);      // (x[t] = 0 for t < j)
-                    v = i < j ? 0.0 : v / at(gi, gi);
-                } else if (!ok) v *= 1e-150;
-                x[i] = v;
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) a.Pn[I * 256 + j * 16 + i] = x[i];
-        }
-    }
-    stamp(11);
-    if (a.prof && tid == 0) a.prof[12] = (unsigned long long)k;
-}
-
-// Y = L^-1 [T | r_thin]: one LANE per right-hand side (column c < n is row c of T^T, c == n is r_thin), 64 right-hand sides
-// per single-wavefront workgroup, blocked by 8 rows.  L (written by upd_chol_kernel) is the same for every lane: it is read
-// through the constant address space, i.e. by scalar loads into SGPRs that feed v_fma_f64 directly -- no LDS, no vector
-// load per L entry -- and the workgroups of one stream spread over three CUs instead of idling 114 threads of one.
-// RB = rows per block step.  Every step re-reads the y of all earlier rows (a lane's own column, 512 coalesced bytes per row and
-// wavefront), so the kernel's memory traffic is k^2 / (2 RB) row reads per wavefront: with all streams of a batch resident at once
-// (6 k wavefronts, 0.3 GB of Y) those reads come from HBM, not from L2, and at RB = 8 they were what the kernel waited for.
-template <int RB>
-__device__ __forceinline__ void upd_fsolve_body(const UpdArgs* __restrict__ arr)
-{
-    AV_FILTER_PRIO();
-    const UpdArgsG a = upd_load(arr, blockIdx.y);
-    if (a.m <= 0 || a.mode != 0) return;
-    const int n = a.n, nc = a.nc, k = (a.kdir > 0 ? a.kdir : upd_k(a.m, nc));
-    if ((int)blockIdx.x * 64 > n) return;
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    const bool act = c <= n;
-    typedef const double __attribute__((address_space(4)))* scalar_ptr;
-    scalar_ptr L = (scalar_ptr)(a.Sbuf);
-    const int ld = a.ld;
-    const av_gptr<double> rcol = a.W + (size_t)nc * a.ldt;
-    const av_gptr<const double> src = (act && c < n) ? a.T + (size_t)c * ld : rcol;
-    const av_gptr<double> y = (act && c < n) ? a.Kt + c : rcol;
-    const size_t st_ = (act && c < n) ? (size_t)ld : 1;
-    for (int i0 = 0; i0 < k; i0 += RB) {
-        double acc[RB];
-#pragma unroll
-        for (int u = 0; u < RB; ++u) acc[u] = (act && i0 + u < k) ? src[i0 + u] : 0.0;
-        // rows i0 .. i0+RB-1 of column q: L^T(q, i0 + u) = Sbuf[q * ld + i0 + u] (i0 and ld are multiples of 8: whole 64-byte lines;
-        // the entries past row k - 1 of the last block multiply into accumulators that are never stored)
-#pragma unroll 4
-        for (int q = 0; q < i0; ++q) {
-            const double yq = act ? y[(size_t)q * st_] : 0.0;
-            scalar_ptr Lq = L + q * ld + i0;
-#pragma unroll
-            for (int u = 0; u < RB; ++u) acc[u] = __builtin_fma(-Lq[u], yq, acc[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            if (i0 + u < k) {
-                // L(i0 + u, i0 + w) = Sbuf[(i0 + u) * ld + i0 + w]
-                scalar_ptr Lu = L + (size_t)min(i0 + u, k - 1) * ld + i0;
-#pragma unroll
-                for (int w = 0; w < u; ++w) acc[u] = __builtin_fma(-Lu[w], acc[w], acc[u]);
-                acc[u] /= Lu[u];
-                if (act) y[(size_t)(i0 + u) * st_] = acc[u];
-            }
-        }
-    }
-}
-__global__ __launch_bounds__(64) void upd_fsolve16_kernel(const UpdArgs* __restrict__ arr) { upd_fsolve_body<16>(arr); }
-
-// P <- sym(P - Y^T Y) in place (msckf.py:597-602): the 4 x 4 sub-tiles on and below the diagonal are formed, each owner
-// reads its sub-tile of P and the mirror sub-tile, then writes both -- every unordered pair {(r,c), (c,r)} has one owner.
-__global__ __launch_bounds__(256) void upd_p_kernel(const UpdArgs* __restrict__ arr)
-{
-    AV_FILTER_PRIO();
-    const UpdArgsG a = upd_load(arr, blockIdx.y);
-    if (a.m <= 0 || a.mode != 0) return;
-    const int n = a.n, k = (a.kdir > 0 ? a.kdir : upd_k(a.m, a.nc));
-    int tr = (int)((sqrtf(8.f * blockIdx.x + 1.f) - 1.f) * 0.5f);
-    while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
-    while (tr * (tr + 1) / 2 > (int)blockIdx.x) --tr;
-    const int tc = blockIdx.x - tr * (tr + 1) / 2;
-    const int r0 = tr * GT, c0 = tc * GT;
-    if (r0 >= n) return;
-    double t[4][4];
-    gemm_tile64(k, r0, c0,
-                [&](int q, int r) { return r < n ? AV_GD(a.Kt)[(size_t)q * a.ld + r] : 0.0; },
-                [&](int q, int c) { return c < n ? AV_GD(a.Kt)[(size_t)q * a.ld + c] : 0.0; }, t, n, n);
-    if (blockIdx.x == 0) {                                   // delta_x = Y^T y_r, by the stream's first tile
-        const auto rcol = a.W + (size_t)a.nc * a.ldt;
-        for (int c = threadIdx.x; c < n; c += 256) {
-            double sacc = 0;
-#pragma unroll 8
-            for (int i = 0; i < k; ++i) sacc += a.Kt[(size_t)i * a.ld + c] * rcol[i];
-            a.dx[c] = a.round > 0 ? a.dx[c] + sacc : sacc;
-        }
-    }
-    const int R0 = r0 + 4 * (threadIdx.x >> 4), C0 = c0 + 4 * (threadIdx.x & 15);
-    if (R0 < C0 || R0 >= n) return;
-    double pr[4][4], pm[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = R0 + i, c = C0 + j;
-            const bool in = r < n && c < n;
-            pr[i][j] = in ? a.P[(size_t)r * a.ld + c] : 0.0;
-            pm[i][j] = in ? a.P[(size_t)c * a.ld + r] : 0.0;
-        }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = R0 + i, c = C0 + j;
-            if (r < n && c < n) {
-                // (inside a diagonal sub-tile the owner holds (r,c) and (c,r) itself; its products are bitwise symmetric --
-                // the same factors summed in the same order -- and so are the two values it writes)
-                const double v = ((pr[i][j] - t[i][j]) + (pm[i][j] - t[i][j])) / 2.;
-                a.P[(size_t)r * a.ld + c] = v;
-                if (R0 != C0) a.P[(size_t)c * a.ld + r] = v;
-            }
-        }
-}
-// (Round 5 archived experiment, profiles/r05/README.md: the three products on 48-wide WAVE tiles, one 576- / 384-thread workgroup per
-//  stream with 6 x 6 results per lane -- three tiles of 48 cover the n <= 141 / k <= 136 of a 20-camera window with 6 % slack where
-//  three tiles of 64 leave 30 % of every edge empty.  Parity-green, but slower: 148.6 k against 155.8 k frames/s on the driver command,
-//  6.24 against 5.87 ms of exclusive chain time.  One workgroup per stream holding 74 KB of LDS keeps two streams on a CU; the 64-wide
-//  kernels spread a stream's tiles over nine short workgroups that fill the gaps the front-end leaves.)
-static inline size_t upd_solve_lds(int k) { return sizeof(double) * ((size_t)k * (k + 1) / 2 + 8); }
 
 // ================================================================================================
 // Information form of the stacked update for streams whose stacked Jacobian touches FEW columns (nc <= INFO_NC: the
@@ -2471,8 +2085,8 @@ __global__ __launch_bounds__(256) void upd_gather_kernel(const UpdArgs* __restri
 // only dependent chain is one n_c-sized Cholesky in a 256-thread workgroup.  This replaces update_front_batch_kernel (a
 // 1024-thread, 128-VGPR Householder workgroup that had to wait ~1 ms for a whole free CU) on the batched path.
 //   upd_rowmap_kernel     stacked row -> row of the block buffer (scan of the gated blocks), int[m] in the stream's Kt buffer
-//   upd_gram_kernel       partial Gram slabs of [Hc | r] per (64 x 64 lower tile, 256-row chunk), in the stream's W buffer
-//   upd_gram_chol_kernel  sum of the slabs -> bordered Cholesky in LDS -> [F | f] written as the k = n_c rows of W
+//   upd_gram_mfma_kernel       Gram matrix of [Hc | r], a 32 x 32 block of the lower triangle per wavefront, into the stream's Sbuf (msckf_mfma.inc)
+//   upd_gram_chol_mfma_kernel  bordered Cholesky by one wavefront -> [F | f] written as the k = n_c rows of W
 // ================================================================================================
 constexpr int GRAM_CHUNK = 256;
 template <typename UA> __device__ __forceinline__ bool upd_front_needed(const UA& a) { return a.m > 0 && a.mode == 0 && a.kdir <= 0 && upd_compress(a.m, a.nc); }
@@ -2480,124 +2094,32 @@ template <typename UA> __device__ __forceinline__ bool upd_front_needed(const UA
 // (n_list_dev != NULL: the list was written on the device -- upd_stack_kernel -- and holds *n_list_dev streams; the workgroups
 //  stride over it.  NULL: one workgroup per listed stream, as launched by the host.)
 template <typename UA> __device__ __forceinline__ void upd_rowmap_one(const UA& a);
-__global__ __launch_bounds__(256) void upd_rowmap_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list, const int* __restrict__ n_list_dev)
+// (one wavefront per workgroup: beside the front-end's single-wavefront workgroups a 256-thread workgroup waits for a free slot on all
+//  four SIMDs of a CU at once -- this kernel, 7 us alone, took 1.1 ms in the shared run)
+__global__ __launch_bounds__(64) void upd_rowmap_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list, const int* __restrict__ n_list_dev)
 {
     AV_FILTER_PRIO();
-    if (n_list_dev) { const int n = *n_list_dev; for (int l = blockIdx.x; l < n; l += gridDim.x) { upd_rowmap_one(upd_load(arr, list[l])); __syncthreads(); } return; }
+    if (n_list_dev) { const int n = *n_list_dev; for (int l = blockIdx.x; l < n; l += gridDim.x) upd_rowmap_one(upd_load(arr, list[l])); return; }
     upd_rowmap_one(upd_load(arr, list[blockIdx.x]));
 }
 template <typename UA> __device__ __forceinline__ void upd_rowmap_one(const UA& a)
 {
     if (!upd_front_needed(a)) return;
-    __shared__ int wsum[4], carry;
     const auto srcrow = (av_gptr<int>)(a.Kt);
-    const int tid = threadIdx.x, nb = a.n_blk;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < nb; b0 += 256) {               // blocks in order: exclusive scan of their lengths, 256 at a time
-        const int b = b0 + tid;
+    const int lane = threadIdx.x, nb = a.n_blk;
+    int carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += 64) {                // blocks in order: exclusive scan of their lengths, a wavefront's worth at a time
+        const int b = b0 + lane;
         const int len = b < nb ? a.blk_len[b] : 0;
         int incl = len;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if ((tid & 63) >= d) incl += t; }
-        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-        __syncthreads();
-        int base = carry;
-        for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
-        const int d0 = base + incl - len;
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        const int d0 = carry + incl - len;
         if (b < nb) { const int r0 = a.blk_row[b]; for (int r = 0; r < len; ++r) srcrow[d0 + r] = r0 + r; }
-        __syncthreads();
-        if (tid == 255) carry = base + incl;
-        __syncthreads();
+        carry += __shfl(incl, 63, 64);
     }
 }
 
-// slab (chunk y) of the Gram matrix of G = [Hc | r] (m x (nc + 1)): tile x of the lower 64 x 64 tiles
-template <typename UA> __device__ __forceinline__ void upd_gram_one(const UA& a);
-__global__ __launch_bounds__(256) void upd_gram_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list, const int* __restrict__ n_list_dev)
-{
-    AV_FILTER_PRIO();
-    if (n_list_dev) { const int n = *n_list_dev; for (int l = blockIdx.z; l < n; l += gridDim.z) { upd_gram_one(upd_load(arr, list[l])); __syncthreads(); } return; }
-    upd_gram_one(upd_load(arr, list[blockIdx.z]));
-}
-template <typename UA> __device__ __forceinline__ void upd_gram_one(const UA& a)
-{
-    if (!upd_front_needed(a)) return;
-    const int m = a.m, nc = a.nc, k1 = nc + 1;
-    const int row0 = blockIdx.y * GRAM_CHUNK;
-    if (row0 >= m) return;
-    const int rows = min(GRAM_CHUNK, m - row0);
-    int tr = (int)((sqrtf(8.f * blockIdx.x + 1.f) - 1.f) * 0.5f);              // triangular tile index -> (tr, tc), tc <= tr
-    while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
-    while (tr * (tr + 1) / 2 > (int)blockIdx.x) --tr;
-    const int tc = blockIdx.x - tr * (tr + 1) / 2;
-    const int r0 = tr * GT, c0 = tc * GT;
-    if (r0 >= k1) return;
-    const auto srcrow = (av_gptr<const int>)(a.Kt) + row0;
-    auto elem = [&](int q, int c) -> double {            // G[row0 + q][c]
-        if (c >= k1) return 0.0;
-        const size_t sr = (size_t)srcrow[q];
-        return c < nc ? AV_GD(a.Hsrc)[sr * a.ld + AV_GI(a.cols)[c]] : AV_GD(a.rsrc)[sr];
-    };
-    double acc[4][4];
-    gemm_tile64(rows, r0, c0, elem, elem, acc, k1, k1);
-    const auto slab = a.W + (size_t)blockIdx.y * k1 * k1;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = r0 + 4 * ty + i, c = c0 + 4 * tx + j;
-            if (r < k1 && c <= r) slab[(size_t)r * k1 + c] = acc[i][j];
-        }
-}
-
-template <typename UA> __device__ __forceinline__ void upd_gram_chol_one(const UA& a, double* Lp);
-__global__ __launch_bounds__(256) void upd_gram_chol_kernel(const UpdArgs* __restrict__ arr, const int* __restrict__ list, const int* __restrict__ n_list_dev)
-{
-    AV_FILTER_PRIO();
-    extern __shared__ double Lp_dyn[];
-    if (n_list_dev) { const int n = *n_list_dev; for (int l = blockIdx.x; l < n; l += gridDim.x) { upd_gram_chol_one(upd_load(arr, list[l]), Lp_dyn); __syncthreads(); } return; }
-    upd_gram_chol_one(upd_load(arr, list[blockIdx.x]), Lp_dyn);
-}
-template <typename UA> __device__ __forceinline__ void upd_gram_chol_one(const UA& a, double* Lp)
-{
-    if (!upd_front_needed(a)) return;
-    const int tid = threadIdx.x, m = a.m, nc = a.nc, k1 = nc + 1;
-    const int nsl = (m + GRAM_CHUNK - 1) / GRAM_CHUNK;
-    auto at = [&](int r, int c) -> double& { return Lp[r * (r + 1) / 2 + c]; };
-    __shared__ double dmax_s[4];
-    double dloc = 0.0;
-    for (int e = tid; e < k1 * k1; e += 256) {
-        const int r = e / k1, c = e - r * k1;
-        if (c > r) continue;
-        double v = 0;
-        for (int y = 0; y < nsl; ++y) v += a.W[(size_t)y * k1 * k1 + (size_t)r * k1 + c];      // fixed order: deterministic
-        if (r == c && r < nc) dloc = fmax(dloc, v);      // (a NaN on the diagonal is dropped by fmax here and caught by the pivot test below)
-        at(r, c) = v;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) dloc = fmax(dloc, __shfl_xor(dloc, d, 64));
-    if ((tid & 63) == 0) dmax_s[tid >> 6] = dloc;
-    __syncthreads();
-    // E = 1e-12 max_i A_ii on every diagonal entry: relative to the LARGEST column, so a column that is (numerically) zero -- a camera
-    // whose block the stacked rows do not constrain -- still gets a pivot well above the rounding of the sums, instead of 1e-12 of
-    // its own rounding noise.  The border pivot (rho - f^T f = the squared residual the columns cannot explain) only has to stay positive.
-    const double eps = 1e-12 * fmax(fmax(dmax_s[0], dmax_s[1]), fmax(dmax_s[2], dmax_s[3])) + 1e-300;
-    for (int r = tid; r < k1; r += 256) at(r, r) = r < nc ? at(r, r) + eps : 2.0 * at(r, r) + 1.0;
-    __syncthreads();
-    const bool ok = chol_packed_lds(Lp, k1, tid);
-    if (!ok && tid == 0 && a.status) *a.status = UPD_BAD_PIVOT;
-    // a Gram matrix that is not positive definite to working precision (or not finite): [F | f] = 0 turns this stream's update into
-    // a no-op (S = s^2 I, delta_x = 0, P unchanged); the stream is stopped on the flag instead of publishing NaN poses
-    const size_t ldt = a.ldt;
-    for (int e = tid; e < nc * nc; e += 256) {           // W[q][row] = F[row][q] = L[q][row] (row <= q), the k = nc rows the back end reads
-        const int q = e / nc, row = e - q * nc;
-        a.W[(size_t)q * ldt + row] = (ok && row <= q) ? at(q, row) : 0.0;
-    }
-    const auto rcol = a.W + (size_t)nc * ldt;
-    for (int row = tid; row < nc; row += 256) rcol[row] = ok ? at(nc, row) : 0.0;
-}
 // ================================================================================================
 // Stacking decisions of remove_lost_features / prune_cam_state_buffer ON THE DEVICE (msckf.py:658-668, 759-763): which gated
 // blocks are stacked (in feature = map order, up to the `> 1500 rows` cut), which camera columns they touch, and how the
@@ -2731,18 +2253,27 @@ __global__ __launch_bounds__(64) void upd_stack_kernel(StackArgs a)
             a.work[8 * s + 1] += 2 * k * n * n + 2 * k * k * n + k * k * k / 3.0 + 2 * k * k * n + 4 * k * n * n;
             if (mm > n) a.work[8 * s + 2] += 2 * mm * n * n - 2.0 / 3.0 * n * n * n;
             a.work[8 * s + 4] += 1.0; a.work[8 * s + 5] += mm;
-            // what the update kernels EXECUTE over the nc touched columns (analytic, tile padding not counted).  Information form
-            // (nc <= 24): Gram m nc^2, b 2 m nc, A P_cc and the 12 x 12 elimination 4 nc^3, the two products with P[:, c]
-            // 2 n nc^2 + 2 n^2 nc.  Cholesky back end: the Gram compression of a stream with more rows than one pass m (nc + 1)^2 +
-            // (nc + 1)^3 / 3 (then kk = nc rows), T^T 2 n nc kk, S kk^2 nc, Cholesky kk^3 / 3, substitution kk^2 (n + 1),
-            // P - Y^T Y n^2 kk (lower tiles) and delta_x 2 kk n
+            // what the update kernels EXECUTE over the nc touched columns (analytic).  Information form (nc <= 24, vector FMAs): Gram
+            // m nc^2, b 2 m nc, A P_cc and the 12 x 12 elimination 4 nc^3, the two products with P[:, c] 2 n nc^2 + 2 n^2 nc.  Cholesky
+            // back end (msckf_mfma.inc): matrix instructions of 16 x 16 x 4, 2,048 flops each, PADDING INCLUDED -- a product over t output
+            // tiles and K summed rows issues t ceil(K / 4) of them: the Gram compression of a stream with more rows than one pass
+            // (lower tiles of nc + 1, K = m; then its factor and kk = nc rows), T^T (tiles of n x kk, K = nc), S (lower tiles of kk, K = nc),
+            // the factor (left-looking: (nb - J) tiles with K = 16 J, plus 4 per sub-diagonal tile for the diagonal block's inverse; the
+            // 16 x 16 diagonal blocks themselves ~2 x 16^3 / 3 vector flops each way), the substitution (per 16 right-hand sides and block
+            // row I: 4 I + 4), P - Y^T Y (lower tiles of n, K = kk) and delta_x 2 kk n
             const double c = (double)nc;
             if (mode == 1) a.work[8 * s + 7] += mm * c * c + 2 * mm * c + 4 * c * c * c + 2 * n * c * c + 2 * n * n * c;
             else {
                 const bool comp = a.compress && m > a.kch;
-                const double kk = comp ? c : mm;
-                a.work[8 * s + 7] += (comp ? mm * (c + 1) * (c + 1) + (c + 1) * (c + 1) * (c + 1) / 3.0 : 0.0)
-                                     + 2 * n * c * kk + kk * kk * c + kk * kk * kk / 3.0 + kk * kk * (n + 1) + n * n * kk + 2 * kk * n;
+                const int kki = comp ? nc : m;
+                auto t16 = [](int x) { return (double)((x + 15) / 16); };
+                auto q4 = [](int x) { return (double)((x + 3) / 4); };
+                auto lower = [](double t) { return t * (t + 1) / 2; };
+                auto factor = [](double nb) { double f = 0; for (int J = 0; J < (int)nb; ++J) f += (nb - J) * 4.0 * J + 4.0 * (nb - J - 1); return f * 2048.0 + nb * 2.0 * 2731.0; };
+                const double tn = t16(n_state), tk = t16(kki);
+                double fl = 2048.0 * (tn * tk * q4(nc) + lower(tk) * q4(nc) + t16(n_state + 1) * 2.0 * tk * (tk + 1) + lower(tn) * q4(kki)) + factor(tk) + 2.0 * kki * n;
+                if (comp) fl += 2048.0 * lower(t16(nc + 1)) * q4(m) + factor(t16(nc + 1));
+                a.work[8 * s + 7] += fl;
             }
         }
     }
@@ -2783,9 +2314,8 @@ static int msckf_lds_opt_in()
         const void* fns[6] = {reinterpret_cast<const void*>(feature_kernel8),
                               reinterpret_cast<const void*>(feature_kernel<16>), reinterpret_cast<const void*>(feature_kernel<64>), reinterpret_cast<const void*>(feature_kernel<256>),
                               reinterpret_cast<const void*>(update_front_kernel), reinterpret_cast<const void*>(update_front_batch_kernel)};
-        const void* fns2[5] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel),
-                               reinterpret_cast<const void*>(upd_chol_kernel), reinterpret_cast<const void*>(upd_info_kernel),
-                               reinterpret_cast<const void*>(upd_gram_chol_kernel)};
+        const void* fns2[3] = {reinterpret_cast<const void*>(update_back_kernel), reinterpret_cast<const void*>(update_back_batch_kernel),
+                               reinterpret_cast<const void*>(upd_info_kernel)};
         for (const void* f : fns2) {
             hipFuncAttributes at;
             hipError_t e = hipFuncGetAttributes(&at, f);
@@ -3017,44 +2547,28 @@ AV_EXPORT int av_msckf_update(av_msckf* c, const int32_t* blk_row_dev, const int
     return AV_OK;
 }
 
+
 #include "msckf_mfma.inc"
 
 // The back end of one round of batched updates: T^T, S, its factor, the substitution, the covariance update -- for all S streams of
 // `arr` (streams without an update of this kind exit on their first instruction).  kmax / nmax: the longest pass / largest state the
-// grids have to cover.  AV_MSCKF_MFMA=0 (A/B) takes the 64 x 64 LDS tile kernels of rounds 3-4 instead of the matrix-instruction ones.
-static inline bool upd_mfma_on() { static const bool on = [] { const char* e = getenv("AV_MSCKF_MFMA"); return !(e && atoi(e) == 0); }(); return on; }
-static inline void launch_upd_back(const UpdArgs* arr, int S, int kmax, int nmax, size_t lds_s, hipStream_t stm, int skipk = 0)
+// grids have to cover.  skipk: timing experiments of the host-store path (AV_MSCKF_SKIP).
+static inline void launch_upd_back(const UpdArgs* arr, int S, int kmax, int nmax, hipStream_t stm, int skipk = 0)
 {
-    if (upd_mfma_on()) {
-        const int bk = (kmax + MBW - 1) / MBW, bn = (nmax + MBW - 1) / MBW;
-        if (!(skipk & 8)) hipLaunchKernelGGL(upd_tt_mfma_kernel, dim3(mfma_grid(bn * bk, S)), dim3(64), 0, stm, arr, S, bn, bk);
-        if (!(skipk & 8)) hipLaunchKernelGGL(upd_s_mfma_kernel, dim3(mfma_grid(bk * (bk + 1) / 2, S)), dim3(64), 0, stm, arr, S, bk);
-        static const bool chol_lds = [] { const char* e = getenv("AV_MSCKF_CHOL"); return e && !strcmp(e, "lds"); }();      // A/B: the 256-thread LDS factor kernel
-        if (!(skipk & 16)) {
-            if (chol_lds) hipLaunchKernelGGL(upd_chol_kernel, dim3(S), dim3(256), lds_s, stm, arr, 0, 1 << 30);
-            else hipLaunchKernelGGL(upd_chol_mfma_kernel, dim3(mfma_grid(1, S)), dim3(64), 0, stm, arr, S);
-        }
-        const int parts = nmax / 16 + 1;
-        if (!(skipk & 32)) hipLaunchKernelGGL(upd_fsolve_mfma_kernel, dim3(mfma_grid(parts, S)), dim3(64), 0, stm, arr, S, parts);
-        if (!(skipk & 64)) hipLaunchKernelGGL(upd_p_mfma_kernel, dim3(mfma_grid(bn * (bn + 1) / 2, S)), dim3(64), 0, stm, arr, S, bn);
-        return;
-    }
-    const int tk = (kmax + GT - 1) / GT, tn = (nmax + GT - 1) / GT;
-    if (!(skipk & 8)) hipLaunchKernelGGL(upd_tt_kernel, dim3(tn * tk, S), dim3(256), 0, stm, arr, tk);
-    if (!(skipk & 8)) hipLaunchKernelGGL(upd_s_kernel, dim3(tk * (tk + 1) / 2, S), dim3(256), 0, stm, arr);
-    if (!(skipk & 16)) hipLaunchKernelGGL(upd_chol_kernel, dim3(S), dim3(256), lds_s, stm, arr, 0, 1 << 30);
-    if (!(skipk & 32)) hipLaunchKernelGGL(upd_fsolve16_kernel, dim3((nmax + 64) / 64, S), dim3(64), 0, stm, arr);
-    if (!(skipk & 64)) hipLaunchKernelGGL(upd_p_kernel, dim3(tn * (tn + 1) / 2, S), dim3(256), 0, stm, arr);
+    const int bk = (kmax + MBW - 1) / MBW, bn = (nmax + MBW - 1) / MBW;
+    if (!(skipk & 8)) hipLaunchKernelGGL(upd_tt_mfma_kernel, dim3(mfma_grid(bn * bk, S)), dim3(64), 0, stm, arr, S, bn, bk);
+    if (!(skipk & 8)) hipLaunchKernelGGL(upd_s_mfma_kernel, dim3(mfma_grid(bk * (bk + 1) / 2, S)), dim3(64), 0, stm, arr, S, bk);
+    if (!(skipk & 16)) hipLaunchKernelGGL(upd_chol_mfma_kernel, dim3(mfma_grid(1, S)), dim3(64), 0, stm, arr, S);
+    const int parts = nmax / 16 + 1;
+    if (!(skipk & 32)) hipLaunchKernelGGL(upd_fsolve_mfma_kernel, dim3(mfma_grid(parts, S)), dim3(64), 0, stm, arr, S, parts);
+    if (!(skipk & 64)) hipLaunchKernelGGL(upd_p_mfma_kernel, dim3(mfma_grid(bn * (bn + 1) / 2, S)), dim3(64), 0, stm, arr, S, bn);
 }
-// Partial Gram slabs of the streams on `list` (n_list_dev: device-written count, the tasks stride over the list; NULL: n_list entries)
-static inline void launch_upd_gram(const UpdArgs* arr, const int* list, const int* n_list_dev, unsigned n_list, unsigned nsl, int k1max, hipStream_t stm)
+// Row compression of the streams on `list` (n_list_dev: device-written count, the tasks stride over the list; NULL: n_list entries):
+// Gram matrix of [Hc | r], then its bordered Cholesky factor -> the k = n_c rows [F | f] of W
+static inline void launch_upd_compress(const UpdArgs* arr, const int* list, const int* n_list_dev, unsigned n_list, int k1max, hipStream_t stm)
 {
-    if (upd_mfma_on()) {
-        const int bk = (k1max + MBW - 1) / MBW, slots = 8 * (int)((n_list + 7) / 8);
-        hipLaunchKernelGGL(upd_gram_mfma_kernel, dim3((unsigned)(bk * (bk + 1) / 2) * nsl * (unsigned)slots), dim3(64), 0, stm, arr, list, n_list_dev, (int)n_list, slots, (int)nsl, bk);
-        return;
-    }
-    const int gt = (k1max + GT - 1) / GT;
-    hipLaunchKernelGGL(upd_gram_kernel, dim3(gt * (gt + 1) / 2, nsl, n_list), dim3(256), 0, stm, arr, list, n_list_dev);
+    const int bk = (k1max + MBW - 1) / MBW, slots = 8 * (int)((n_list + 7) / 8);
+    hipLaunchKernelGGL(upd_gram_mfma_kernel, dim3((unsigned)(bk * (bk + 1) / 2) * (unsigned)slots), dim3(64), 0, stm, arr, list, n_list_dev, (int)n_list, slots, bk);
+    hipLaunchKernelGGL(upd_gram_chol_mfma_kernel, dim3(n_list), dim3(64), 0, stm, arr, list, n_list_dev, (int)n_list);
 }
 #include "msckf_batch.inc"
