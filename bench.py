@@ -308,6 +308,7 @@ class CompletePath(object):
         self.frames, self.host, self.imu_fe, self.imu_flt, self.frame_ts = frames, host, imu_fe, imu_flt, frame_ts
         self.msckf_s, self.push_s, self.poses = [0.0], [0.0], []      # poses: (frame index, out[S,12]) of every filter step
         self.step_times = None
+        self.n_frames = None                                           # set by the caller that knows how many frames `frames` holds
 
     def run_fe(self, k):
         i, t, gy, ac = self.imu_fe[k]
@@ -384,8 +385,15 @@ class CompletePath(object):
         # serial: front-end and filter strictly alternate (exclusive GPU times add up) -- the warm-up steps of the default run (the filter's
         # chain timed with the GPU to itself: roofline_msckf.exclusive), or the whole run as a diagnostic (AV_BENCH_SERIAL=1)
         serial = os.environ.get('AV_BENCH_SERIAL') or getattr(self, 'force_serial', False)
+        # The next frame's pyramids are enqueued BEFORE this frame's feature message is handed over (av_frontend_prestage): the filter's
+        # chain then starts behind the pyramid kernels instead of beside them (its first kernel and the pyramid kernel halve each other:
+        # both want most of a CU's LDS).  Same kernels per step, same results; AV_BENCH_PRESTAGE=0 is the A/B.
+        prestage = (not serial) and (not self.host) and os.environ.get('AV_BENCH_PRESTAGE', '1') != '0' and self.n_frames is not None
         for k in range(k_begin, k_end):
             self.run_fe(k)
+            if prestage and k + 1 < self.n_frames:
+                a, b = self.frames(k + 1)
+                self.eng.prestage(a, b)
             if serial:
                 torch.cuda.synchronize()
                 self.fe_excl_s = getattr(self, 'fe_excl_s', 0.0)
@@ -592,6 +600,7 @@ def main():
                         (lambda k: (host0[k], host1[k])) if host0 is not None else (lambda k: (img0[k], img1[k])),
                         host0 is not None, imu_steps, imu_steps_f, frame_ts)
     path.step_times = [] if os.environ.get('AV_BENCH_STEP_TIMES') else None     # diagnostic: wall time at which every frame's features were handed to the filter
+    path.n_frames = len(frame_ts)
     msckf_s, push_s, poses0, step_times = path.msckf_s, path.push_s, path.poses, path.step_times
     run, run_pipelined = path.run, path.run_pipelined
 

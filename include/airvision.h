@@ -173,6 +173,13 @@ int av_frontend_push_imu_batch(av_frontend* fe, const int32_t* stream_idx, const
 int av_frontend_step(av_frontend* fe, const uint8_t* img0_dev, const uint8_t* img1_dev, int64_t img_stride,
                      const double* timestamps, void* stream);
 /* Same with host images (the drop-in boundary hands over numpy arrays): copies H2D, steps. */
+/* Builds the pyramids of the images the NEXT av_frontend_step will be given, now, behind whatever is enqueued on `stream` (needs
+ * AV_FE_INPUTS_PERSIST; the step that follows with the same pointers skips its own pyramid launch; results are identical -- the
+ * launch only changes its place in the stream).  pipeline.py:46-150 builds a frame's pyramids when the frame arrives; a caller
+ * that knows its next frame (a replay, a queue of camera frames: streaming/dataset.py:93-158) can have them built while the
+ * filter works on the frame before. */
+int av_frontend_prestage(av_frontend* fe, const uint8_t* img0_dev, const uint8_t* img1_dev, int64_t img_stride, void* stream);
+
 int av_frontend_step_host(av_frontend* fe, const uint8_t* img0_host, const uint8_t* img1_host, int64_t img_stride,
                           const double* timestamps, void* stream);
 

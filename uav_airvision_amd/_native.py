@@ -74,6 +74,7 @@ SIGNATURES = {
     'av_frontend_push_imu': (C.c_int, [_P, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     'av_frontend_push_imu_batch': (C.c_int, [_P, _P, _P, _P, C.c_int]),
     'av_frontend_step': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double), _P]),
+    'av_frontend_prestage': (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     'av_frontend_step_host': (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double), _P]),
     'av_frontend_frames_reserve': (C.c_int, [_P, C.c_int]),
     'av_frontend_frames_upload': (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int64, _P]),

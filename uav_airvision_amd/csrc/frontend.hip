@@ -627,6 +627,8 @@ struct av_frontend {
     // image outlives the step that gets it: always for av_frontend_step_host (the library's own staging slots), and for
     // av_frontend_step when the engine was created with AV_FE_INPUTS_PERSIST (include/airvision.h).
     const uint8_t* l0_img[3] = {nullptr, nullptr, nullptr}; int64_t l0_stride[3] = {0, 0, 0};
+    // av_frontend_prestage: the pyramids of the NEXT step's images are already built (same slots, same launch): that step skips its own launch
+    bool pre_on = false, pre_wrote_l0 = true; const uint8_t* pre_img0 = nullptr; const uint8_t* pre_img1 = nullptr; int64_t pre_stride = 0;
     void* zero_region = nullptr; size_t zero_bytes = 0;
     // Shared frame store (av_frontend_frames_reserve / _upload / av_frontend_step_frames): every DISTINCT stereo frame of a sweep is
     // uploaded, pyramided and FAST-scanned once and stays resident; the streams that replay it -- the offset streams of one
@@ -788,8 +790,10 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
         I_prev0 = I_cur0 = fe->fs.l0_in_place ? fe->fs.img : nullptr; I_cur1 = fe->fs.l0_in_place ? fe->fs.img + hw : nullptr;
     } else {
         bool wrote_l0 = true;
-        { Span sp(fe, 0, st);
+        if (fe->pre_on && fe->pre_img0 == img0 && fe->pre_img1 == img1 && fe->pre_stride == img_stride) wrote_l0 = fe->pre_wrote_l0;      // built by av_frontend_prestage
+        else { Span sp(fe, 0, st);
           if ((rc = av_launch_pyramid(img0, img1, img_stride, S, 2, fe->geom, fe->pyr, sstride, slotb, cur0, 2, st, !(inputs_persist && !zc_off), &wrote_l0))) return rc; }
+        fe->pre_on = false;
         fe->l0_img[cur0] = wrote_l0 ? nullptr : img0; fe->l0_img[2] = wrote_l0 ? nullptr : img1;
         fe->l0_stride[cur0] = fe->l0_stride[2] = img_stride;
         I_prev0 = fe->l0_img[par]; st_prev0 = fe->l0_stride[par];      // (first frame: nothing is tracked from it)
@@ -1015,6 +1019,28 @@ AV_EXPORT int av_frontend_push_imu_batch(av_frontend* fe, const int32_t* stream_
         int rc = av_frontend_push_imu(fe, stream_idx[i], timestamps[i], gyro + 3 * (size_t)i);
         if (rc) return rc;
     }
+    return AV_OK;
+}
+
+// The pyramids of the images the NEXT av_frontend_step will get, enqueued now (behind the step just enqueued): that step then starts
+// with its tracking launch.  Same kernels, same slots, same results -- only their place in the stream moves.  A caller that hands a
+// step's feature message to the batched filter AFTER this call (av_msckf_batch_submit_dev copies it on this stream) starts the
+// filter's chain behind the pyramid kernels instead of beside them: the filter's first kernel (39 KB of LDS, 4 x 128 registers per
+// stream) and the pyramid kernel (all 160 KB of LDS at six workgroups per CU) otherwise halve each other (profiles/r05/README.md).
+// Needs AV_FE_INPUTS_PERSIST (the images are read again by the step itself); a step that comes with other images builds its own.
+AV_EXPORT int av_frontend_prestage(av_frontend* fe, const uint8_t* img0_dev, const uint8_t* img1_dev, int64_t img_stride, void* stream)
+{
+    if (!fe || !img0_dev || !img1_dev || img_stride < (int64_t)fe->d.w * fe->d.h) { av_set_error("av_frontend_prestage: bad arguments"); return AV_E_INVALID; }
+    if (!(fe->cfg.flags & AV_FE_INPUTS_PERSIST)) { av_set_error("av_frontend_prestage: the engine was created without AV_FE_INPUTS_PERSIST"); return AV_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    AV_HIP(hipSetDevice(fe->device));
+    static const bool zc_off = [] { const char* e = getenv("AV_FE_ZERO_COPY"); return e && atoi(e) == 0; }();
+    const int cur0 = fe->parity ^ 1;         // the slots the next step will call cur0 / 2
+    int rc;
+    bool wrote_l0 = true;
+    { Span sp(fe, 0, st);
+      if ((rc = av_launch_pyramid(img0_dev, img1_dev, img_stride, fe->d.S, 2, fe->geom, fe->pyr, 3 * fe->lay.bytes, fe->lay.bytes, cur0, 2, st, zc_off, &wrote_l0))) return rc; }
+    fe->pre_on = true; fe->pre_wrote_l0 = wrote_l0; fe->pre_img0 = img0_dev; fe->pre_img1 = img1_dev; fe->pre_stride = img_stride;
     return AV_OK;
 }
 

@@ -632,7 +632,8 @@ __device__ __forceinline__ bool lk_track_g16_body(const LKArgs& a)
 // filter's single-wavefront tasks, each of which takes ONE slot on ONE SIMD, a CU with three free slots starts nothing -- every
 // resident filter wavefront can keep a whole LK workgroup out: complete path 161.6 -> 168.9 k.  (profiles/r05/README.md)
 template <int WIN> __global__ __launch_bounds__(64, 5) void lk_track_g16_kernel(LKArgs a) { lk_track_g16_body<WIN, 5, false, 4>(a); }
-// AV_LK_WG=256 (A/B): four wavefronts (16 points) per workgroup, rounds 2-4's launch shape
+// AV_LK_WG=256 (A/B): four wavefronts (16 points) per workgroup, rounds 2-4's launch shape.  (Two wavefronts per workgroup lie in
+// between: front-end alone 218.3 k against 220.2 k, complete path 166.2 against 168.7 k.  profiles/r05/README.md)
 template <int WIN> __global__ __launch_bounds__(256, 5) void lk_track_g16_w4_kernel(LKArgs a) { lk_track_g16_body<WIN, 5>(a); }
 // (Forward and backward pass of a stereo match as ONE launch -- the 16 lanes that tracked a point forward track it back, three launches
 //  fewer per front-end step -- was built and measured in round 5: front-end alone 207.9 / 206.2 k against 206.1 / 206.8 k frames/s, one
@@ -884,10 +885,11 @@ int av_launch_lk(const uint8_t* pyrI, const uint8_t* pyrJ, int64_t stream_stride
     }
     const bool prof = lk_prof_on();
     static const bool w1 = [] { const char* e = getenv("AV_LK_WG"); return !(e && atoi(e) == 256); }();      // one wavefront per workgroup; AV_LK_WG=256 (A/B): four
-    const dim3 grid = lk_g16_grid(a, n_set, launch_pts, (w1 && !prof) ? 4 : 16);
+    const int wgp = (prof || !w1) ? 256 : 64;
+    const dim3 grid = lk_g16_grid(a, n_set, launch_pts, wgp / 16);
     a.prof = g_lk_prof;
     if (prof) hipLaunchKernelGGL(lk_track_g16_prof_kernel<15>, grid, dim3(256), 0, st, a);
-    else if (w1) hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(64), 0, st, a);
+    else if (wgp == 64) hipLaunchKernelGGL(lk_track_g16_kernel<15>, grid, dim3(64), 0, st, a);
     else hipLaunchKernelGGL(lk_track_g16_w4_kernel<15>, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;

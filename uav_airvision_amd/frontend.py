@@ -122,6 +122,16 @@ class FrontendEngine(object):
             N.check(N.lib().av_frontend_step(self._h, N.dptr(img0), N.dptr(img1), self.height * self.width, ts, self._stream()))
         self._keep = (self._keep[1] if self._keep else None, (img0, img1))       # this frame's and the previous frame's tensors stay alive
 
+    def prestage(self, img0, img1):
+        """Build the pyramids of the NEXT step's images now (av_frontend_prestage): `step` with the same tensors then starts with its
+        tracking launch.  Same results; the engine must have been created with inputs_persist=True."""
+        S = self.n_streams
+        assert img0.is_cuda and img1.is_cuda and img0.dtype == torch.uint8 and img1.dtype == torch.uint8
+        assert tuple(img0.shape) == (S, self.height, self.width) == tuple(img1.shape) and img0.is_contiguous() and img1.is_contiguous()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().av_frontend_prestage(self._h, N.dptr(img0), N.dptr(img1), self.height * self.width, self._stream()))
+        self._pre = (img0, img1)                                                # alive until the step that uses them
+
     def step_host(self, img0, img1, timestamps):
         """numpy uint8 [S,h,w] (or [h,w] when S == 1)."""
         S = self.n_streams
