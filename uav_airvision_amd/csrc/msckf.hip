@@ -874,7 +874,10 @@ struct PropArgs {
 // 21 x 6N block in global memory become one).
 constexpr int PROP_LDS_DOUBLES = 5 * IMU_DIM * IMU_DIM + IMU_DIM * 12;      // F, F2, Phi, T, Q, G
 // EXT: the six work matrices live in `ext` (PROP_LDS_DOUBLES doubles of LDS the caller also uses for something else at other times)
-template <bool EXT = false>
+// NT: threads of the workgroup -- 256, or 64 (dk_cov: the device-resident filter runs a stream's covariance steps in ONE wavefront; the
+// barriers below are then wavefront-local and the scalar preparation sits on neighbouring lanes instead of on the first lanes of
+// three wavefronts)
+template <bool EXT = false, int NT = 256>
 __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s = nullptr, double* PhiT = nullptr, double* ext = nullptr)
 {
     __shared__ double own[EXT ? 1 : PROP_LDS_DOUBLES];
@@ -884,11 +887,13 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
     __shared__ double Rwi[9], Rnull[9], Rnew[9], u[3], sv[3], w1[3], w2[3];
     const int tid = threadIdx.x;
     const int N = IMU_DIM;
-    for (int i = tid; i < N * N; i += 256) F[i] = 0.0;
-    for (int i = tid; i < N * 12; i += 256) G[i] = 0.0;
+    constexpr int Q1 = NT == 256 ? 64 : 1, Q2 = NT == 256 ? 128 : 2;          // lanes of the three quaternion conversions (0, Q1, Q2)
+    constexpr int R1 = NT == 256 ? 64 : 9, R2 = NT == 256 ? 128 : 22, R3 = NT == 256 ? 192 : 43;      // first lanes of the side jobs (beside lanes 0 .. 8)
+    for (int i = tid; i < N * N; i += NT) F[i] = 0.0;
+    for (int i = tid; i < N * 12; i += NT) G[i] = 0.0;
     // the scalar preparation is spread over the first lanes of three wavefronts (it used to be lane 0's alone: with the back end batched
     // this serial stretch, not the 21 x 21 products, was most of a sample's time)
-    if ((tid & 63) == 0 && tid < 192) quat_to_rot(tid == 0 ? a.q_old : (tid == 64 ? a.q_null : a.q_new), tid == 0 ? Rwi : (tid == 64 ? Rnull : Rnew));
+    if (tid == 0 || tid == Q1 || tid == Q2) quat_to_rot(tid == 0 ? a.q_old : (tid == Q1 ? a.q_null : a.q_new), tid == 0 ? Rwi : (tid == Q1 ? Rnull : Rnew));
     __syncthreads();
     if (tid < 9) {
         const int r = tid / 3, c = tid - 3 * r;
@@ -906,11 +911,11 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
         G[(3 + r) * 12 + 3 + c] = r == c ? 1.0 : 0.0;
         G[(6 + r) * 12 + 6 + c] = -Rwi[c * 3 + r];
         G[(9 + r) * 12 + 9 + c] = r == c ? 1.0 : 0.0;
-    } else if (tid == 64) {
+    } else if (tid == R1) {
         for (int r = 0; r < 3; ++r) u[r] = Rnull[r * 3] * a.gravity[0] + Rnull[r * 3 + 1] * a.gravity[1] + Rnull[r * 3 + 2] * a.gravity[2];
         double uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
         for (int r = 0; r < 3; ++r) sv[r] = u[r] / uu;
-    } else if (tid == 128) {
+    } else if (tid == R2) {
         double dv[3] = {a.v_null[0] - a.v_new[0], a.v_null[1] - a.v_new[1], a.v_null[2] - a.v_new[2]};
         double dp[3] = {a.dt * a.v_null[0] + a.p_null[0] - a.p_new[0], a.dt * a.v_null[1] + a.p_null[1] - a.p_new[1], a.dt * a.v_null[2] + a.p_null[2] - a.p_new[2]};
         const double* g = a.gravity;
@@ -924,24 +929,24 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
     // matrices themselves (a bit mask per row / column) and the sums run over the non-zeros only, in the same ascending order: a
     // skipped term is an exact zero, so the results are bit-identical to the dense sums.
     __shared__ unsigned frow[IMU_DIM], fcol[IMU_DIM], prow[IMU_DIM];
-    for (int i = tid; i < N * N; i += 256) F[i] *= a.dt;                       // Fdt
-    if (tid >= 128 && tid < 128 + N) {                                          // (scaling by dt keeps the pattern; a dt of 0 only zeroes more)
-        const int r = tid - 128; unsigned m = 0;
+    for (int i = tid; i < N * N; i += NT) F[i] *= a.dt;                       // Fdt
+    if (tid >= R2 && tid < R2 + N) {                                            // (scaling by dt keeps the pattern; a dt of 0 only zeroes more)
+        const int r = tid - R2; unsigned m = 0;
         for (int k = 0; k < N; ++k) if (F[r * N + k] != 0.0) m |= 1u << k;
         frow[r] = m;
-    } else if (tid >= 192 && tid < 192 + N) {
-        const int c = tid - 192; unsigned m = 0;
+    } else if (tid >= R3 && tid < R3 + N) {
+        const int c = tid - R3; unsigned m = 0;
         for (int k = 0; k < N; ++k) if (F[k * N + c] != 0.0) m |= 1u << k;
         fcol[c] = m;
     }
     __syncthreads();
-    for (int i = tid; i < N * N; i += 256) {                                    // Fdt^2
+    for (int i = tid; i < N * N; i += NT) {                                    // Fdt^2
         int r = i / N, c = i - r * N; double s = 0;
         for (unsigned m = frow[r]; m; m &= m - 1) { const int k = __builtin_ctz(m); s += F[r * N + k] * F[k * N + c]; }
         F2[i] = s;
     }
     __syncthreads();
-    for (int i = tid; i < N * N; i += 256) {                                    // Fdt^3, Phi
+    for (int i = tid; i < N * N; i += NT) {                                    // Fdt^3, Phi
         int r = i / N, c = i - r * N; double s = 0;
         for (unsigned m = fcol[c]; m; m &= m - 1) { const int k = __builtin_ctz(m); s += F2[r * N + k] * F[k * N + c]; }
         Phi[i] = (r == c ? 1.0 : 0.0) + F[i] + F2[i] / 2. + s / 6.;
@@ -952,18 +957,18 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
         int r = tid / 3, c = tid % 3; double s = 0;
         for (int k = 0; k < 3; ++k) s += Rnew[r * 3 + k] * Rnull[c * 3 + k];
         Phi[r * N + c] = s;
-    } else if (tid >= 64 && tid < 70) {                                         // OC-KF corrections of rows 6..8 and 12..14
-        const int t6 = tid - 64, blk = t6 / 3, r = t6 % 3;
+    } else if (tid >= R1 && tid < R1 + 6) {                                     // OC-KF corrections of rows 6..8 and 12..14
+        const int t6 = tid - R1, blk = t6 / 3, r = t6 % 3;
         const int row = (blk == 0 ? 6 : 12) + r;
         const double* wv = blk == 0 ? w1 : w2;
         const double p0 = Phi[row * N], p1 = Phi[row * N + 1], p2 = Phi[row * N + 2];
         const double Au = p0 * u[0] + p1 * u[1] + p2 * u[2];
         const double d = Au - wv[r];
         Phi[row * N] = p0 - d * sv[0]; Phi[row * N + 1] = p1 - d * sv[1]; Phi[row * N + 2] = p2 - d * sv[2];
-    } else if (tid >= 128 && tid < 128 + N) {
+    } else if (tid >= R2 && tid < R2 + N) {
         // the pattern of the finished Phi: the entries the two patches rewrite at this moment (columns 0 .. 2 of rows 0 .. 2, 6 .. 8, 12 .. 14)
         // count as non-zero whatever they hold
-        const int r = tid - 128; unsigned m = 0;
+        const int r = tid - R2; unsigned m = 0;
         for (int k = 0; k < N; ++k) if (Phi[r * N + k] != 0.0) m |= 1u << k;
         if (r < 3 || (r >= 6 && r < 9) || (r >= 12 && r < 15)) m |= 7u;
         prow[r] = m;
@@ -971,12 +976,12 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
     __syncthreads();
     // three products with the finished Phi, side by side: T = Phi G (21 x 12, for Q = Phi G Qc G^T Phi^T dt), F2 = Phi P11, and in
     // batched mode Q <- Phi PhiT (the frame's accumulated transition; Q is only a buffer here, the noise term is added below)
-    for (int i = tid; i < N * 12; i += 256) {
+    for (int i = tid; i < N * 12; i += NT) {
         int r = i / 12, c = i - r * 12; double s = 0;
         for (unsigned m = prow[r]; m; m &= m - 1) { const int k = __builtin_ctz(m); s += Phi[r * N + k] * G[k * 12 + c]; }
         T[i] = s;
     }
-    for (int i = tid; i < N * N; i += 256) {
+    for (int i = tid; i < N * N; i += NT) {
         int r = i / N, c = i - r * N; double s = 0;
         if (P11s) { for (unsigned m = prow[r]; m; m &= m - 1) { const int k = __builtin_ctz(m); s += Phi[r * N + k] * P11s[k * N + c]; } }
         else      { for (unsigned m = prow[r]; m; m &= m - 1) { const int k = __builtin_ctz(m); s += Phi[r * N + k] * a.P[(size_t)k * a.ld + c]; } }
@@ -989,7 +994,7 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
     }
     __syncthreads();
     // P11 <- Phi P11 Phi^T + Q
-    for (int i = tid; i < N * N; i += 256) {
+    for (int i = tid; i < N * N; i += NT) {
         int r = i / N, c = i - r * N; double s = 0, q = 0;
         for (int k = 0; k < 12; ++k) q += T[r * 12 + k] * a.noise[k / 3] * T[c * 12 + k];
         q = q * a.dt;
@@ -999,7 +1004,7 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
     __syncthreads();
     if (P11s) {
         // batched: symmetrised IMU block back to LDS ((P + P^T)/2 per sample, msckf.py:334-335), PhiT <- Phi PhiT
-        for (int i = tid; i < N * N; i += 256) {
+        for (int i = tid; i < N * N; i += NT) {
             int r = i / N, c = i - r * N;
             PhiT[i] = Q[i];
             P11s[i] = (F[r * N + c] + F[c * N + r]) / 2.;
@@ -1011,13 +1016,13 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
     const int nc = a.n - N;
     for (int c0 = 0; c0 < nc; c0 += N) {
         const int w = min(N, nc - c0);
-        for (int i = tid; i < N * w; i += 256) {
+        for (int i = tid; i < N * w; i += NT) {
             int r = i / w, c = i - r * w; double s = 0;
             for (unsigned m = prow[r]; m; m &= m - 1) { const int k = __builtin_ctz(m); s += Phi[r * N + k] * a.P[(size_t)k * a.ld + N + c0 + c]; }
             T[i] = s;
         }
         __syncthreads();
-        for (int i = tid; i < N * w; i += 256) {
+        for (int i = tid; i < N * w; i += NT) {
             int r = i / w, c = i - r * w;
             a.P[(size_t)r * a.ld + N + c0 + c] = T[i];
             a.P[(size_t)(N + c0 + c) * a.ld + r] = T[i];
@@ -1025,7 +1030,7 @@ __device__ __forceinline__ void propagate_body(const PropArgs& a, double* P11s =
         __syncthreads();
     }
     // write P11 symmetrised ((P + P^T)/2 of msckf.py:334-335; the cross blocks are exact transposes already)
-    for (int i = tid; i < N * N; i += 256) {
+    for (int i = tid; i < N * N; i += NT) {
         int r = i / N, c = i - r * N;
         a.P[(size_t)r * a.ld + c] = (F[r * N + c] + F[c * N + r]) / 2.;
     }
@@ -1077,12 +1082,13 @@ __global__ __launch_bounds__(256) void propagate_batch_kernel(const PropArgs* ar
 // ================================================================================================
 struct AugArgs { double* P; int n, ld; double R_ic[9]; double sk[9]; };     // sk = skew(R_w_i^T t_c_i)
 
+template <int NT = 256>
 __device__ __forceinline__ void augment_body(const AugArgs& a)
 {
     __shared__ double J[6 * IMU_DIM];
     __shared__ double C[36];
     const int tid = threadIdx.x, N = IMU_DIM, n = a.n;
-    for (int i = tid; i < 6 * N; i += 256) J[i] = 0.0;
+    for (int i = tid; i < 6 * N; i += NT) J[i] = 0.0;
     __syncthreads();
     if (tid < 9) {
         int r = tid / 3, c = tid % 3;
@@ -1094,7 +1100,7 @@ __device__ __forceinline__ void augment_body(const AugArgs& a)
     }
     __syncthreads();
     // new rows: J P[:21, :n]
-    for (int i = tid; i < 6 * n; i += 256) {
+    for (int i = tid; i < 6 * n; i += NT) {
         int r = i / n, c = i - r * n; double s = 0;
         for (int k = 0; k < N; ++k) s += J[r * N + k] * a.P[(size_t)k * a.ld + c];
         a.P[(size_t)(n + r) * a.ld + c] = s;
@@ -1107,7 +1113,7 @@ __device__ __forceinline__ void augment_body(const AugArgs& a)
         C[tid] = s;
     }
     __syncthreads();
-    for (int i = tid; i < 6 * n; i += 256) {
+    for (int i = tid; i < 6 * n; i += NT) {
         int r = i / n, c = i - r * n;
         a.P[(size_t)c * a.ld + n + r] = a.P[(size_t)(n + r) * a.ld + c];
     }
@@ -1129,13 +1135,13 @@ __device__ __forceinline__ void remove_cam_body(double* P, double* scratch, int 
 {
     // compact into scratch, then copy back (single workgroup; n <= 147)
     const int tid = threadIdx.x, m = n - 6;
-    for (int i = tid; i < m * m; i += 256) {
+    for (int i = tid; i < m * m; i += (int)blockDim.x) {
         int r = i / m, c = i - r * m;
         int sr = r < start ? r : r + 6, sc = c < start ? c : c + 6;
         scratch[i] = P[(size_t)sr * ld + sc];
     }
     __syncthreads();
-    for (int i = tid; i < m * m; i += 256) {
+    for (int i = tid; i < m * m; i += (int)blockDim.x) {
         int r = i / m, c = i - r * m;
         P[(size_t)r * ld + c] = scratch[i];
     }
@@ -1146,14 +1152,14 @@ __device__ __forceinline__ void remove_cam_body(double* P, double* scratch, int 
 __device__ __forceinline__ void remove_two_cams_body(double* P, double* scratch, int n, int ld, int s0, int s1)
 {
     const int tid = threadIdx.x, m = n - 12;
-    for (int i = tid; i < m * m; i += 256) {
+    for (int i = tid; i < m * m; i += (int)blockDim.x) {
         const int r = i / m, c = i - r * m;
         if (r < s0 && c < s0) continue;
         const int sr = r < s0 ? r : (r + 6 < s1 ? r + 6 : r + 12), sc = c < s0 ? c : (c + 6 < s1 ? c + 6 : c + 12);
         scratch[i] = P[(size_t)sr * ld + sc];
     }
     __syncthreads();
-    for (int i = tid; i < m * m; i += 256) {
+    for (int i = tid; i < m * m; i += (int)blockDim.x) {
         const int r = i / m, c = i - r * m;
         if (r < s0 && c < s0) continue;
         P[(size_t)r * ld + c] = scratch[i];
