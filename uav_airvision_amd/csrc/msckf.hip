@@ -819,7 +819,7 @@ __device__ __forceinline__ void feature_one(const FeatArgs& a, const int slot, d
 // small fp64 steps, so the register budget is capped for 8 waves per SIMD (the Jacobian phase spills, but only its two
 // active lanes touch scratch) -- twice the features in flight per CU.
 template <int TEAM> __global__ __launch_bounds__(256) void feature_kernel(FeatArgs a);
-template <> __global__ __launch_bounds__(256) void feature_kernel<256>(FeatArgs a) { feature_body<256>(a); }
+template <> __global__ __launch_bounds__(256, 4) void feature_kernel<256>(FeatArgs a) { feature_body<256>(a); }
 template <> __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(256) void feature_kernel<64>(FeatArgs a) { feature_body<64>(a); }
 template <> __global__ __attribute__((amdgpu_waves_per_eu(4, 8))) __launch_bounds__(256) void feature_kernel<16>(FeatArgs a) { feature_body<16>(a); }
 // The device-resident filter's build of the 16-lane kernel: 207 registers, nothing spilled, two waves per SIMD.  Measured per 2,048-stream
