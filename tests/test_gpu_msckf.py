@@ -134,15 +134,21 @@ def test_end_to_end_matches_reference_golden(dropin, cfg, name):
     flt.close()
 
 
-@pytest.mark.parametrize('groups,store', [(1, 'device'), (2, 'device'), (1, 'host'), (2, 'host')])
+@pytest.mark.parametrize('groups,store', [(1, 'device'), (2, 'device'), (1, 'device-w64'), (1, 'host'), (2, 'host')])
 def test_batched_filters_match_reference_golden_and_oracle(cfg, groups, store, monkeypatch):
     """Three independent streams stepped together by the C++/HIP batched filter: stream 0 reproduces the
     reference's own golden run; all streams follow the numpy oracle frame by frame.  groups=2 splits the batch
     into two concurrently stepped stream groups (streams {0,1} and {2}), as large batches are by default.
     store='host' runs the same checks through the host-bookkeeping path (AV_MSCKF_STORE=host: the observation map and the
     selections on the host, the numeric phases by the same kernels) -- the fallback for shapes the device-resident store
-    does not cover; it stays in the library only as long as it stays tested."""
+    does not cover; it stays in the library only as long as it stays tested.  store='device-w64': the per-stream kernels of the
+    device-resident path as ONE wavefront per stream (AV_DK_WG=64), the launch shape batches of 1,024 streams and more take by
+    themselves -- three streams would get four wavefronts."""
     monkeypatch.setenv('AV_MSCKF_GROUPS', str(groups))
+    monkeypatch.delenv('AV_DK_WG', raising=False)
+    if store == 'device-w64':
+        monkeypatch.setenv('AV_DK_WG', '64')
+        store = 'device'
     if store == 'host':
         monkeypatch.setenv('AV_MSCKF_STORE', 'host')
     else:
