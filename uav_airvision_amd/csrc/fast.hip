@@ -336,6 +336,10 @@ int av_launch_fast(const uint8_t* img, int64_t img_stride, int img_pitch, int bo
     dim3 grid = xcd_map ? dim3((unsigned)(tx * ty) * 8u * (unsigned)((n_img + 7) / 8)) : dim3(tx, ty, n_img);
     // (An occupancy throttle -- unused dynamic LDS holding the detector to 6 / 5 / 4 workgroups per CU so that the filter's kernels find
     //  room beside it -- was measured in round 5: 156.9 / 154.7 / 149.7 k against 157.5 k frames/s.  profiles/r05/README.md)
+    // (The same 64 x 48 tile worked by two / one wavefront instead of four -- a workgroup of fewer wavefronts is easier to place beside the
+    //  filter's single-wavefront tasks -- measured in round 5: detector 1.71 / 2.43 against 1.51 ms alone, 2.60 / 3.38 against 2.21 ms in
+    //  the shared run, 170.2 / 159.5 against 173.4 k frames/s: with 19 KB of LDS per tile the CU then holds half / a quarter of the
+    //  wavefronts.  What the detector needs is a wavefront that walks a column of small tiles.  profiles/r05/README.md)
     hipLaunchKernelGGL(fast_kernel, grid, dim3(256), 0, st, a);
     AV_LAUNCH_CHECK();
     return AV_OK;
