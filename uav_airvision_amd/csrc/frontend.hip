@@ -82,7 +82,10 @@ __device__ __forceinline__ int cell_of(const FeDev& d, float x, float y)
     return (int)(y / (float)d.gh) * d.grid_col + (int)(x / (float)d.gw);
 }
 
-// ordered compaction position inside a 256-thread block; `base` is a running total in registers
+// workgroup size of the per-stream glue kernels below: 256 threads, or 64 (one wavefront per stream: step_impl picks by batch size)
+#define NTB ((int)blockDim.x)
+#define NWB ((int)(blockDim.x >> 6))
+// ordered compaction position inside the workgroup; `base` is a running total in registers
 __device__ __forceinline__ int block_ordered_pos(bool flag, int& base, int* lds4)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -91,8 +94,7 @@ __device__ __forceinline__ int block_ordered_pos(bool flag, int& base, int* lds4
     if (lane == 0) lds4[wv] = __popcll(b);
     __syncthreads();
     int off = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { int c = lds4[i]; if (i < wv) off += c; tot += c; }
+    for (int i = 0; i < NWB; ++i) { int c = lds4[i]; if (i < wv) off += c; tot += c; }
     int pos = base + off + lane_prefix;
     base += tot;
     __syncthreads();
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) void track_gate_kernel(FeDev d)
     if (fe_idle(d, s)) return;
     const int n = d.trk_count[s];
     int base = 0;
-    for (int i0 = 0; i0 < n; i0 += 256) {
+    for (int i0 = 0; i0 < n; i0 += NTB) {
         const int i = i0 + threadIdx.x;
         const size_t t = (size_t)s * d.NT + i;
         bool keep = false; float x = 0, y = 0;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void rebin_kernel(FeDev d, int par)
     if (fe_idle(d, s)) return;
     const int n = d.sv_count[s];
     int base = 0;
-    for (int i0 = 0; i0 < n; i0 += 256) {
+    for (int i0 = 0; i0 < n; i0 += NTB) {
         const int i = i0 + threadIdx.x;
         const size_t t = (size_t)s * d.NT + i;
         bool keep = false;
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256) void rebin_kernel(FeDev d, int par)
     if (threadIdx.x == 0) { d.cur_count[s] = base; d.counters[s * NCNT + CNT_MATCHED] = base; }
     __syncthreads();
     uint8_t* m = d.mask + (size_t)s * d.w * d.h;
-    for (int q = threadIdx.x; q < base * 49; q += 256) {
+    for (int q = threadIdx.x; q < base * 49; q += NTB) {
         int f = q / 49, j = q - f * 49;
         const size_t o = (size_t)s * d.NT + f;
         mask_box(d, m, d.cur_p0[2 * o], d.cur_p0[2 * o + 1], j, 0);
@@ -262,19 +264,19 @@ __global__ __launch_bounds__(256) void select_kernel(FeDev d)
         const int nt = d.n_tiles;
         constexpr int BK = 32, BU = 5;
         if (threadIdx.x == 0) tmax = 0;
-        for (int c = threadIdx.x; c < d.C; c += 256) ccnt[c] = 0;
+        for (int c = threadIdx.x; c < d.C; c += NTB) ccnt[c] = 0;
         __syncthreads();
         int mx = 0;
-        for (int t = threadIdx.x; t < nt; t += 256) { const int n = d.tile_count[(size_t)ts * nt + t]; tpre[t] = n; mx = max(mx, n); }
+        for (int t = threadIdx.x; t < nt; t += NTB) { const int n = d.tile_count[(size_t)ts * nt + t]; tpre[t] = n; mx = max(mx, n); }
         if (mx > 0) atomicMax(&tmax, mx);
         __syncthreads();
         const int maxcount = tmax;
         for (int kb = 0; kb < maxcount; kb += BK)
-            for (int j0 = threadIdx.x; j0 < nt * BK; j0 += 256 * BU) {
+            for (int j0 = threadIdx.x; j0 < nt * BK; j0 += NTB * BU) {
                 uint32_t word[BU]; int x[BU], y[BU]; bool ok[BU]; uint8_t mk[BU];
 #pragma unroll
                 for (int u = 0; u < BU; ++u) {
-                    const int j = j0 + 256 * u, t = j / BK, k = kb + (j % BK);
+                    const int j = j0 + NTB * u, t = j / BK, k = kb + (j % BK);
                     ok[u] = j < nt * BK && k < tpre[min(t, nt - 1)];
                     word[u] = ok[u] ? d.tile_kp[((size_t)ts * nt + t) * d.tile_cap + k] : 0u;
                 }
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256) void select_kernel(FeDev d)
         __syncthreads();
         if (threadIdx.x == 0) { int tot = 0; for (int c = 0; c < d.C; ++c) tot += ccnt[c]; d.counters[s * NCNT + CNT_FAST] = tot; }
     }
-    for (int c = threadIdx.x; c < d.C; c += 256) {
+    for (int c = threadIdx.x; c < d.C; c += NTB) {
         int n = min(ccnt[c], d.cell_cap);
         cnt[c] = first ? n : min(n, d.gmax);
     }
@@ -318,13 +320,13 @@ __global__ __launch_bounds__(256) void select_kernel(FeDev d)
         d.counters[s * NCNT + CNT_CAND] = acc;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c <= d.C; c += 256) d.cand_off[s * (d.C + 1) + c] = off[c];
+    for (int c = threadIdx.x; c <= d.C; c += NTB) d.cand_off[s * (d.C + 1) + c] = off[c];
     // Round 1 of the stereo matching (see cand_round2_kernel): the first R1 candidates of every cell, all of them on the first frame
     {
         __shared__ int r1n;
         if (threadIdx.x == 0) r1n = 0;
         __syncthreads();
-        for (int c = threadIdx.x; c < d.C; c += 256) {
+        for (int c = threadIdx.x; c < d.C; c += NTB) {
             const int take = first ? cnt[c] : min(cnt[c], CAND_R1);
             const int base = atomicAdd(&r1n, take);                     // order of the list is irrelevant: results are written by index
             for (int r = 0; r < take; ++r) d.r1_list[(size_t)s * d.CC + base + r] = off[c] + r;
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256) void select_kernel(FeDev d)
     }
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int c = wv; c < d.C; c += 4) {
+    for (int c = wv; c < d.C; c += NWB) {
         const uint32_t* list = d.cell_kp + ((size_t)s * d.C + c) * d.cell_cap;
         const int n = min(ccnt[c], d.cell_cap);
         const int take = cnt[c];
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256) void select_kernel(FeDev d)
     }
     __syncthreads();
     const int total = off[d.C];
-    for (int i = threadIdx.x; i < total; i += 256) {
+    for (int i = threadIdx.x; i < total; i += NTB) {
         const size_t o = (size_t)s * d.CC + i;
         uint32_t raster = AV_KP_RASTER_MASK - (d.cand_key[o] & AV_KP_RASTER_MASK);
         float y = (float)(raster / (uint32_t)d.w), x = (float)(raster % (uint32_t)d.w);
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(256) void cand_round2_kernel(FeDev d)
     const bool first = d.first_frame[s] != 0;
     if (threadIdx.x == 0) r2n = 0;
     __syncthreads();
-    for (int c = threadIdx.x; c < d.C; c += 256) {
+    for (int c = threadIdx.x; c < d.C; c += NTB) {
         const int b = coff[c], e = coff[c + 1];
         const int r1 = first ? (e - b) : min(e - b, CAND_R1);
         int inl = 0;
@@ -416,7 +418,7 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* k, int n)
     for (int size = 2; size <= n; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
-            for (int t = threadIdx.x; t < (n >> 1); t += 256) {
+            for (int t = threadIdx.x; t < (n >> 1); t += NTB) {
                 int lo = 2 * t - (t & (stride - 1));
                 int hi = lo + stride;
                 bool up = (lo & size) == 0;
@@ -453,17 +455,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(FeDev d, int par)
     const int nxt = par ^ 1;
 
     // A. stereo gate of the candidates matched in round 2 (round 1 was gated by cand_round2_kernel; 0 = never needed)
-    for (int i = threadIdx.x; i < ncand; i += 256) {
+    for (int i = threadIdx.x; i < ncand; i += NTB) {
         const size_t o = (size_t)s * d.CC + i;
         if (d.cand_inl[o] == 2) d.cand_inl[o] = stereo_gate(d, d.cand_p0[2 * o], d.cand_p0[2 * o + 1], d.cand_init[2 * o], d.cand_init[2 * o + 1],
                                     d.cand_p1[2 * o], d.cand_p1[2 * o + 1], d.cand_st[o], d.cand_back[2 * o], d.cand_back[2 * o + 1]) ? 1 : 0;
     }
-    for (int c = threadIdx.x; c < d.C; c += 256) trk_n[c] = 0;
+    for (int c = threadIdx.x; c < d.C; c += NTB) trk_n[c] = 0;
     if (threadIdx.x == 0) flags[0] = 0;
     __syncthreads();
 
     // B. per cell: top grid_min inliers by (response desc, raster asc)
-    for (int c = wv; c < d.C; c += 4) {
+    for (int c = wv; c < d.C; c += NWB) {
         const int b = coff[c], e = coff[c + 1];
         uint32_t last = 0xFFFFFFFFu;
         int r = 0;
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FeDev d, int par)
         if (lane == 0) sel_n[c] = r;
     }
     // D. tracked features per cell
-    for (int i = threadIdx.x; i < T; i += 256) atomicAdd(&trk_n[d.cur_cell[(size_t)s * d.NT + i]], 1);
+    for (int i = threadIdx.x; i < T; i += NTB) atomicAdd(&trk_n[d.cur_cell[(size_t)s * d.NT + i]], 1);
     __syncthreads();
 
     // C. prefixes (C <= 256 cells: serial is fine)
@@ -503,16 +505,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(FeDev d, int par)
     const int M = T + n_new;
 
     // E. sort keys: cell | (lifetime key when the cell will be pruned) | insertion index
-    for (int j = threadIdx.x; j < d.NSORT; j += 256) keys[j] = ~0ull;
+    for (int j = threadIdx.x; j < d.NSORT; j += NTB) keys[j] = ~0ull;
     __syncthreads();
-    for (int i = threadIdx.x; i < T; i += 256) {
+    for (int i = threadIdx.x; i < T; i += NTB) {
         const size_t o = (size_t)s * d.NT + i;
         const int c = d.cur_cell[o];
         const bool pruned = trk_n[c] + sel_n[c] > d.gmax;
         unsigned long long lk = pruned ? (LIFE_MAX - (unsigned long long)d.cur_life[o]) : 0ull;
         keys[i] = ((unsigned long long)c << 48) | (lk << 24) | (unsigned long long)i;
     }
-    for (int q = threadIdx.x; q < d.C * d.gmin; q += 256) {
+    for (int q = threadIdx.x; q < d.C * d.gmin; q += NTB) {
         const int c = q / d.gmin, r = q - c * d.gmin;
         if (r < sel_n[c]) {
             const int ins = T + sel_pre[c] + r;
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FeDev d, int par)
 
     // G. pruned grid of this frame, cell-major
     const long long id0 = d.next_id[s];
-    for (int j = threadIdx.x; j < M; j += 256) {
+    for (int j = threadIdx.x; j < M; j += NTB) {
         const unsigned long long k = keys[j];
         const int c = (int)(k >> 48), ins = (int)(k & 0xFFFFFFull);
         const int rank = j - cell_start[c];
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FeDev d, int par)
     // feature_publisher.py:97-107 dtype rule: cam0 coordinates stay float64 iff any
     // published cam0 point is a FAST tuple (= a feature created this frame); cam1 is always float32.
     const bool f64 = flags[0] != 0;
-    for (int j = threadIdx.x; j < n_out; j += 256) {
+    for (int j = threadIdx.x; j < n_out; j += NTB) {
         const size_t o = (size_t)s * d.MAXF + j;
         double u0, v0, u1, v1;
         av_undistort(d.cam0, d.I3, (double)d.feat_p0[nxt][2 * o], (double)d.feat_p0[nxt][2 * o + 1], u0, v0);
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FeDev d, int par)
     }
     // restore the FAST mask to all ones
     uint8_t* m = d.mask + (size_t)s * d.w * d.h;
-    for (int q = threadIdx.x; q < T * 49; q += 256) {
+    for (int q = threadIdx.x; q < T * 49; q += NTB) {
         int f = q / 49, j = q - f * 49;
         const size_t o = (size_t)s * d.NT + f;
         mask_box(d, m, d.cur_p0[2 * o], d.cur_p0[2 * o + 1], j, 1);
@@ -813,27 +815,31 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
         return av_launch_fast(fast_img, sstride, fe->geom.pitch[0], AV_PYR_BORDER, nullptr, 0, S, d.w, d.h, fe->cfg.fast_threshold,
                               nullptr, nullptr, 0, d.tile_kp, d.tile_count, d.counters + CNT_OVF, NCNT, fs);
     };
+    // per-stream glue kernels: 256-thread workgroups.  (AV_FE_GLUE_WG=64, one wavefront per stream -- bit-exact, the kernels take any
+    // workgroup size -- measured in round 5: glue 0.78 against 0.66 ms alone, 0.94 against 1.07 beside the filter, and the detector next
+    // to them 2.46 against 2.31: front-end alone 216.9 against 220.3 k, complete path 173.3 against 174.3 k.  profiles/r05/README.md)
+    static const int gwg = [] { const char* e = getenv("AV_FE_GLUE_WG"); return (e && atoi(e) == 64) ? 64 : 256; }();
     { Span sp(fe, 3, st);
       hipLaunchKernelGGL(track_prepare_kernel, dim3((d.NT + 255) / 256, S), dim3(256), 0, st, d, par);
       AV_LAUNCH_CHECK(); }
     { Span sp(fe, 1, st);
       if ((rc = av_launch_lk(P_prev0, P_cur0, sstride, S, fe->geom, d.trk_prev, d.trk_next, d.trk_status, d.trk_count, d.NT, d.NT, fe->lk, st, nullptr, I_prev0, st_prev0, I_cur0, img_stride, map_prev, map_cur))) return rc; }
     { Span sp(fe, 3, st);
-      hipLaunchKernelGGL(track_gate_kernel, dim3(S), dim3(256), 0, st, d);
+      hipLaunchKernelGGL(track_gate_kernel, dim3(S), dim3(gwg), 0, st, d);
       AV_LAUNCH_CHECK(); }
     { Span sp(fe, 1, st);
       if ((rc = av_launch_lk(P_cur0, P_cur1, sstride, S, fe->geom, d.sv_p0, d.sv_p1, d.sv_st, d.sv_count, d.NT, d.NT, fe->lk, st, nullptr, I_cur0, img_stride, I_cur1, img_stride, map_cur, map_cur))) return rc; }
     { Span sp(fe, 1, st);
       if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.sv_p1, d.sv_back, d.sv_st2, d.sv_count, d.NT, d.NT, fe->lk, st, nullptr, I_cur1, img_stride, I_cur0, img_stride, map_cur, map_cur))) return rc; }
     { Span sp(fe, 3, st);
-      hipLaunchKernelGGL(rebin_kernel, dim3(S), dim3(256), 0, st, d, par);
+      hipLaunchKernelGGL(rebin_kernel, dim3(S), dim3(gwg), 0, st, d, par);
       AV_LAUNCH_CHECK(); }
     // (FAST on a second HIP stream beside the temporal / stereo LK launches -- it reads only the new cam0 image and is first needed by
     //  select_kernel -- was measured in round 5: front-end alone 196.6 k against 205.1 k frames/s, complete path 157.7 against 157.3 k:
     //  the LK launches slow down by more than the detector's time; profiles/r05/README.md)
     if (!frames && (rc = launch_fast(st))) return rc;                           // (frame store: FAST ran when the frame was uploaded)
     { Span sp(fe, 3, st);
-      hipLaunchKernelGGL(select_kernel, dim3(S), dim3(256), sizeof(int) * (3 * d.C + 1 + d.n_tiles + 1), st, d);
+      hipLaunchKernelGGL(select_kernel, dim3(S), dim3(gwg), sizeof(int) * (3 * d.C + 1 + d.n_tiles + 1), st, d);
       AV_LAUNCH_CHECK(); }
     const int r1_launch = any_first ? d.CC : d.C * (d.gmax < CAND_R1 ? d.gmax : CAND_R1);
     { Span sp(fe, 1, st);
@@ -841,7 +847,7 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
     { Span sp(fe, 1, st);
       if ((rc = av_launch_lk(P_cur1, P_cur0, sstride, S, fe->geom, d.cand_p1, d.cand_back, d.cand_st2, d.r1_count, d.CC, r1_launch, fe->lk, st, d.r1_list, I_cur1, img_stride, I_cur0, img_stride, map_cur, map_cur))) return rc; }
     { Span sp(fe, 3, st);
-      hipLaunchKernelGGL(cand_round2_kernel, dim3(S), dim3(256), 0, st, d);
+      hipLaunchKernelGGL(cand_round2_kernel, dim3(S), dim3(gwg), 0, st, d);
       AV_LAUNCH_CHECK(); }
     if (d.gmax > CAND_R1) {                       // round 2: the rest of the cells that are still short of inliers (usually none)
         const int r2_launch = d.C * (d.gmax - CAND_R1);
@@ -852,7 +858,7 @@ int step_impl(av_frontend* fe, const uint8_t* img0, const uint8_t* img1, int64_t
     }
     size_t fin_lds = sizeof(unsigned long long) * d.NSORT + sizeof(int) * (2 * d.C * d.gmin + 2 * d.C + 3 * (d.C + 1) + 4);
     { Span sp(fe, 3, st);
-      hipLaunchKernelGGL(finalize_kernel, dim3(S), dim3(256), fin_lds, st, d, par);
+      hipLaunchKernelGGL(finalize_kernel, dim3(S), dim3(gwg), fin_lds, st, d, par);
       AV_LAUNCH_CHECK(); }
     fe->parity = par ^ 1;
     if (frames) { AV_HIP(hipEventRecord(fe->fs.stepped, st)); fe->fs.any_step = true; }
