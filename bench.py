@@ -395,6 +395,7 @@ class CompletePath(object):
                 a, b = self.frames(k + 1)
                 self.eng.prestage(a, b)
             if serial:
+                if hasattr(self.eng, 'drain'): self.eng.drain()
                 torch.cuda.synchronize()
                 self.fe_excl_s = getattr(self, 'fe_excl_s', 0.0)
             t1 = time.perf_counter()
@@ -437,6 +438,9 @@ def main():
     ap.add_argument('--cpu-seed', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--dry-run', action='store_true', help='exercise launcher + rank plumbing on CPU (gloo), no GPU work, not a measurement')
     ap.add_argument('--frontend-only', action='store_true', help='time only the image front-end (BASELINE configs[1] literally: MSCKF not on the GPU)')
+    ap.add_argument('--pipelines', type=int, default=int(os.environ.get('AV_BENCH_PIPELINES', '1')),
+                    help='independent pipelines per GPU: the streams are split into this many parts, each with its own front-end engine, batched filter, host thread '
+                         'and HIP streams (uav_airvision_amd/pipelines.py); 1 = one engine and one filter for all streams')
     args = ap.parse_args()
     bench_rc = 0
     if args.cpu_baseline_worker:               # child of cpu_baseline_all_cores: CPU only, exits before torch is imported
@@ -583,11 +587,25 @@ def main():
         lo_hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else (0, -1)
         fe_stream = torch.cuda.Stream(device=dev, priority=(min(lo_hi) if os.environ['AV_FE_PRIO'] == '2' else max(lo_hi)))
         torch.cuda.set_stream(fe_stream)
-    eng = FrontendEngine(cfg, n_streams=S, device=local_rank, inputs_persist=True)      # every frame of the run is resident in HBM
+    # Several independent pipelines on the GPU (--pipelines P): P engines + P filters of S / P streams, each on its own host thread and
+    # HIP streams; same streams, same kernels, same per-stream results.  Only for the device-resident hand-over and the front-end-only loop.
+    n_pipes = max(1, min(args.pipelines, S))
+    if args.host_images or os.environ.get('AV_MSCKF_STORE') == 'host' or fe_stream is not None:
+        n_pipes = 1
     flt = None
-    if with_msckf:
-        from uav_airvision_amd.msckf_ops import BatchedMSCKF
-        flt = BatchedMSCKF(cfg, S, device=local_rank, rows_cap=4096 if 5 * eng.max_features + 64 <= 4096 else None, max_features=eng.max_features)
+    if n_pipes > 1:
+        from uav_airvision_amd.pipelines import EngineSet, FilterSet
+        eng = EngineSet(cfg, S, n_pipes, device=local_rank, inputs_persist=True)
+        if with_msckf:
+            flt = FilterSet(cfg, eng, device=local_rank, rows_cap=4096 if 5 * eng.max_features + 64 <= 4096 else None, max_features=eng.max_features)
+            if not flt.device_resident():
+                sys.stderr.write('bench.py: --pipelines needs the device-resident filter\n')
+                return 4
+    else:
+        eng = FrontendEngine(cfg, n_streams=S, device=local_rank, inputs_persist=True)      # every frame of the run is resident in HBM
+        if with_msckf:
+            from uav_airvision_amd.msckf_ops import BatchedMSCKF
+            flt = BatchedMSCKF(cfg, S, device=local_rank, rows_cap=4096 if 5 * eng.max_features + 64 <= 4096 else None, max_features=eng.max_features)
     filt_stream = torch.cuda.Stream(device=dev) if flt is not None else None
 
     host0 = host1 = None
@@ -605,6 +623,8 @@ def main():
     run, run_pipelined = path.run, path.run_pipelined
 
     def barrier():
+        if hasattr(eng, 'drain'):
+            eng.drain()                               # the pipelines' workers have enqueued everything they were handed
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -722,6 +742,7 @@ def main():
                               'null-space + gate, QR-compressed update, pruning) on the published features'
                               if with_msckf else 'MSCKF not in the step (configs[1] literally)')),
                 'streams_per_gpu': S, 'unique_rendered_streams': U, 'parallelism': 'stream-sharded x%d' % world,
+                'pipelines_per_gpu': n_pipes,
                 'replication': ('%d distinct streams (own scene, trajectory speed 0.7-1.6x, 0-2 s phase; stream 0 = the stream the CPU path replays), '
                                 'replicated to %d per GPU with +-2 grey levels of per-replica noise' % (U, S)) +
                                ('; the filters of the odd replicas start one step later, so half of the filters run the two-camera prune on even and half on odd steps'
@@ -759,6 +780,9 @@ def main():
                         'profiles/r05/valu_issue_microbench.json and lk_dma_experiment.md; 1,024 SIMDs at 2.4 GHz) is the bound that binds. In the complete path the span also contains the higher-priority filter kernels '
                         'that preempt it.',
                 'avg_launch_ms': lk_avg_ms, 'launches': lk_n, 'algorithmic_bytes_per_launch': lk_bytes_per_launch,
+                # --pipelines P: a launch covers S / P streams and runs beside the kernels of the other P - 1 pipelines (their launches are summed
+                # over the pipelines: `launches` = 7 P per step): `achieved` / `frac` are what ONE launch gets of the machine it shares
+                'streams_per_launch': S // n_pipes, 'pipelines': n_pipes,
                 # same kernel, same inputs, timed in the front-end-only loop that follows (no filter kernels sharing the GPU)
                 'avg_launch_ms_frontend_only': (timing_fe['lk'][0] / max(timing_fe['lk'][1], 1)) if timing_fe else None,
             },
