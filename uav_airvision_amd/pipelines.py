@@ -4,8 +4,9 @@ filter (the methods `bench.py` and `sweep.py` call).
 
 Why (profiles/r05/README.md, `scripts/two_engines.py`): an engine's step is one in-order chain of ~20 launches on one HIP stream --
 every kernel boundary drains the machine before the next kernel fills it, and the chain's kernels are bound by different things (LK by
-VALU issue, the pyramids by HBM, the glue kernels by latency).  Independent pipelines fill each other's gaps: FRONT-END ALONE 220 ->
-234-236 k frames/s with two to four pipelines of the same 2,048 streams (`bench.py --frontend-only --pipelines P`).  In the complete path
+VALU issue, the pyramids by HBM, the glue kernels by latency).  Independent pipelines fill each other's gaps: FRONT-END ALONE 218.5 ->
+229.3 k frames/s with two pipelines of the same 2,048 streams (`bench.py --frontend-only --pipelines 2`; 233-236 k in the front-end-only leg
+that follows a complete-path run; four pipelines: 215-236 k, no better than two).  In the complete path
 the batched filter's kernels already are that second tenant: there one pipeline stays the best (174.3 k against 160.6 / 167.5 / 165.5-170.4 k
 with 2 / 3 / 4), which is why `--pipelines` defaults to 1.  Same kernels, same results per stream -- streams never interact
 (`modules/vio.py` runs one pipeline per process).
